@@ -1,0 +1,409 @@
+"""CPU oracle -- TEST INFRASTRUCTURE ONLY.
+
+A plain eager-PyTorch fp32 restatement of the reference's generative-policy hot path, written
+from the reference's published behaviour (file:line cited per function, paths relative to
+/root/reference).  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import this file; the product package (``generativerl_preview_amd``)
+never does and fails loudly without its HIP library.
+
+Parity status: every function here is pinned by ``tests/golden/*.npz`` (vectors produced by the
+reference's own classes, see ``tests/golden/make_golden.py``) in ``tests/test_oracle_golden.py``
+-- EXCEPT the time stepping itself (``euler_ode`` / ``euler_maruyama``): the reference delegates
+that to torchdyn / torchdiffeq / torchsde, which are neither vendored, pinned nor installed, so
+their fixed-grid Euler / dt-driven Euler-Maruyama semantics are restated from those libraries'
+documented behaviour: **stepping parity unpinned** (SURVEY.md section 8c).
+
+All tensors are float32 torch CPU tensors; ``sd`` is a mapping ``state_dict key -> tensor`` using
+the reference's key layout (``model.model.backbone.sort_t.0.weight`` ...).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------- network
+def fourier_embed(t, W):
+    """grl/neural_network/encoders.py:85-86 -- cat[sin(t W), cos(t W)]."""
+    p = t[..., None] * W[None, :]
+    return torch.cat([torch.sin(p), torch.cos(p)], dim=-1)
+
+
+def _lin(sd, key, x):
+    return F.linear(x, sd[key + ".weight"], sd[key + ".bias"])
+
+
+def _res_block(sd, pre, te, x):
+    """grl/neural_network/__init__.py:224-234 (ctor :200-222)."""
+    h1 = F.silu(_lin(sd, pre + "dense1.0", x)) + _lin(sd, pre + "time_mlp.1", F.silu(te))
+    h2 = F.silu(_lin(sd, pre + "dense2.0", h1))
+    if (pre + "modify_x.weight") in sd:
+        return h2 + _lin(sd, pre + "modify_x", x)
+    return h2 + x
+
+
+def resnet_forward(sd, pre, t_emb, x, cond=None):
+    """TemporalSpatialResidualNet.forward, grl/neural_network/__init__.py:329-342."""
+    if cond is not None:
+        tc = torch.cat([t_emb, F.silu(_lin(sd, pre + "pre_sort_condition.0", cond))], dim=-1)
+    else:
+        tc = t_emb
+    te = _lin(sd, pre + "sort_t.2", F.silu(_lin(sd, pre + "sort_t.0", tc)))
+    d = [_res_block(sd, pre + "first_block.", te, x)]
+    i = 0
+    while (pre + "down_block.%d.dense1.0.weight" % i) in sd:
+        d.append(_res_block(sd, pre + "down_block.%d." % i, te, d[i]))
+        i += 1
+    u = _res_block(sd, pre + "middle_block.", te, d[-1])
+    i = 0
+    while (pre + "up_block.%d.dense1.0.weight" % i) in sd:
+        u = _res_block(sd, pre + "up_block.%d." % i, te, torch.cat([u, d[-i - 1]], dim=-1))
+        i += 1
+    return _lin(sd, pre + "last_block", torch.cat([u, d[0]], dim=-1))
+
+
+def concat_mlp_forward(sd, pre, *xs):
+    """ConcatenateMLP / MultiLayerPerceptron with SiLU, grl/neural_network/__init__.py:548-583."""
+    h = torch.cat(xs, dim=-1)
+    i = 0
+    while (pre + "model.model.linear%d.weight" % (i + 1)) in sd:
+        h = F.silu(_lin(sd, pre + "model.model.linear%d" % i, h))
+        i += 1
+    return _lin(sd, pre + "model.model.linear%d" % i, h)
+
+
+def intrinsic_forward(sd, t, x, cond=None, pre="model.", backbone="TemporalSpatialResidualNet"):
+    """IntrinsicModel.forward, grl/generative_models/intrinsic_model.py:54-75
+    (t_encoder = GaussianFourierProjectionTimeEncoder, identity x/condition encoders)."""
+    te = fourier_embed(t, sd[pre + "model.t_encoder.W"])
+    if backbone == "TemporalSpatialResidualNet":
+        return resnet_forward(sd, pre + "model.backbone.", te, x, cond)
+    if backbone == "ConcatenateMLP":
+        ins = (te, x) if cond is None else (te, x, cond)
+        return concat_mlp_forward(sd, pre + "model.backbone.", *ins)
+    raise ValueError(backbone)
+
+
+# ----------------------------------------------------------------------------- schedules
+class Path:
+    """GaussianConditionalProbabilityPath, grl/numerical_methods/probability_path.py:90-448
+    (``linear_vp_sde`` and ``gvp``), reproduced as written -- including d_scale_dt's missing
+    beta_0 term (:342-343) and gvp's g^2 (:222-229)."""
+
+    def __init__(self, cfg):
+        self.type = cfg["type"]
+        self.b0 = float(cfg.get("beta_0", 0.1))
+        self.b1 = float(cfg.get("beta_1", 20.0))
+        self.t_max = float(cfg.get("t_max", 1.0))
+        assert self.type in ("linear_vp_sde", "gvp"), self.type
+
+    def f(self, t):
+        if self.type == "linear_vp_sde":
+            return -0.5 * (self.b0 + t * (self.b1 - self.b0))
+        return -0.5 * torch.pi * torch.tan(torch.pi * t / 2.0)
+
+    def g2(self, t):
+        if self.type == "linear_vp_sde":
+            return self.b0 + t * (self.b1 - self.b0)
+        s = torch.sin(torch.pi * t * 0.5)
+        return torch.pi * s + s * s * torch.tan(torch.pi * t * 0.5)
+
+    def g(self, t):
+        return torch.sqrt(self.g2(t))
+
+    def scale(self, t):
+        if self.type == "linear_vp_sde":
+            return torch.exp(-0.25 * t ** 2 * (self.b1 - self.b0) - 0.5 * t * self.b0)
+        return torch.cos(0.5 * torch.pi * t)
+
+    def d_scale(self, t):
+        if self.type == "linear_vp_sde":
+            return -0.5 * t * (self.b1 - self.b0) * self.scale(t)
+        return -0.5 * torch.pi * torch.sin(0.5 * torch.pi * t)
+
+    def std(self, t):
+        if self.type == "linear_vp_sde":
+            return torch.sqrt(1.0 - self.scale(t) ** 2)
+        return torch.sin(0.5 * torch.pi * t)
+
+    def d_std(self, t):
+        if self.type == "linear_vp_sde":
+            return -self.d_scale(t) * self.scale(t) / self.std(t)
+        return 0.5 * torch.pi * torch.cos(0.5 * torch.pi * t)
+
+    def cov(self, t):
+        if self.type == "linear_vp_sde":
+            return 1.0 - self.scale(t) ** 2
+        s = torch.sin(0.5 * torch.pi * t)
+        return s * s
+
+
+def _b(v, x):
+    """DiffusionProcess broadcast: (B,) -> x.shape, diffusion_process.py:55-57."""
+    return v[(...,) + (None,) * (x.dim() - v.dim())].expand(x.shape) if x.dim() > v.dim() else v
+
+
+# ----------------------------------------------------------------------------- head conversions
+def score_head(model_type, path, net, t, x):
+    """ScoreFunction.forward, model_functions/score_function.py:44-81."""
+    if model_type == "noise_function":
+        return -net / _b(path.std(t), x)
+    if model_type == "score_function":
+        return net
+    if model_type == "velocity_function":
+        return -(net - _b(path.f(t), x) * x) * 2.0 / _b(path.g2(t), x)
+    if model_type == "data_prediction_function":
+        return -(x - _b(path.scale(t), x) * net) / _b(path.cov(t), x)
+    raise NotImplementedError(model_type)
+
+
+def noise_head(model_type, path, net, t, x):
+    """NoiseFunction.forward, model_functions/noise_function.py:62-78."""
+    if model_type == "noise_function":
+        return net
+    if model_type == "score_function":
+        return -net * _b(path.std(t), x)
+    if model_type == "velocity_function":
+        return (net - _b(path.f(t), x) * x) * 2.0 * _b(path.std(t), x) / _b(path.g2(t), x)
+    if model_type == "data_prediction_function":
+        return (x - _b(path.scale(t), x) * net) / _b(path.std(t), x)
+    raise NotImplementedError(model_type)
+
+
+def velocity_head(model_type, path, net, t, x):
+    """VelocityFunction.forward, model_functions/velocity_function.py:54-79
+    (the data_prediction branch raises in the reference -- shape bug -- and is not restated)."""
+    if model_type == "noise_function":
+        return _b(path.f(t), x) * x + 0.5 * _b(path.g2(t), x) / _b(path.std(t), x) * net
+    if model_type == "score_function":
+        return _b(path.f(t), x) * x - 0.5 * _b(path.g2(t), x) * net
+    if model_type == "velocity_function":
+        return net
+    raise NotImplementedError(model_type)
+
+
+def data_head(model_type, path, net, t, x):
+    """DataPredictionFunction.forward, model_functions/data_prediction_function.py:62-84."""
+    s, sig = _b(path.scale(t), x), _b(path.std(t), x)
+    if model_type == "noise_function":
+        return (x - sig * net) / s
+    if model_type == "score_function":  # as written: -std * x (not x)
+        return (-sig * x + _b(path.cov(t), x) * net) / s
+    if model_type == "velocity_function":
+        return ((_b(path.f(t), x) * x - net) * 2.0 * _b(path.cov(t), x) / _b(path.g2(t), x) + x) / s
+    if model_type == "data_prediction_function":
+        return net
+    raise NotImplementedError(model_type)
+
+
+# ----------------------------------------------------------------------------- drifts
+def reverse_ode_drift(model_type, path, fn, t, x, T=1.0):
+    """DiffusionProcess.reverse_ode, generative_models/diffusion_process.py:853-919.
+    ``fn(tau, x)`` is the model (or the guided score when model_type == 'score_function')."""
+    tau = T - t
+    if model_type == "score_function":
+        return -_b(path.f(tau), x) * x + 0.5 * _b(path.g2(tau), x) * fn(tau, x)
+    if model_type == "noise_function":
+        return -_b(path.f(tau), x) * x - 0.5 * _b(path.g2(tau), x) * fn(tau, x) / _b(path.std(tau), x)
+    if model_type == "velocity_function":
+        return -fn(tau, x)
+    if model_type == "data_prediction_function":
+        D = 0.5 * _b(path.g2(tau), x) / _b(path.cov(tau), x)
+        return -(_b(path.f(tau), x) + D) * x + _b(path.scale(tau), x) * D * fn(tau, x)
+    raise NotImplementedError(model_type)
+
+
+def reverse_sde_drift(model_type, path, rpath, fn, t, x, T=1.0):
+    """DiffusionProcess.reverse_sde drift, diffusion_process.py:742-851."""
+    tau = T - t
+    g2, gr2 = _b(path.g2(tau), x), _b(rpath.g2(tau), x)
+    if model_type == "score_function":
+        return -_b(path.f(tau), x) * x + 0.5 * (g2 + gr2) * fn(tau, x)
+    if model_type == "noise_function":
+        return -_b(path.f(tau), x) * x - 0.5 * (g2 + gr2) * fn(tau, x) / _b(path.std(tau), x)
+    if model_type == "velocity_function":
+        v = fn(tau, x)
+        r = gr2 / (g2 + 1e-8)
+        return -v - (v - _b(path.f(tau), x) * x) * r
+    if model_type == "data_prediction_function":
+        D = 0.5 * (g2 + gr2) / _b(path.cov(tau), x)
+        return -(_b(path.f(tau), x) + D) * x + _b(path.scale(tau), x) * D * fn(tau, x)
+    raise NotImplementedError(model_type)
+
+
+def reverse_sde_diffusion(rpath, t, x, T=1.0):
+    """diffusion_process.py:775-779 -- g_rev(T - t) broadcast to x."""
+    return _b(rpath.g(T - t), x)
+
+
+def energy_guidance(sd, t, x, cond, scale, pre="energy_guidance.model."):
+    """EnergyGuidance.calculate_energy_guidance,
+    diffusion_model/energy_conditional_diffusion_model.py:67-92: scale * d/dx sum_rows E(t,x,c)."""
+    with torch.enable_grad():
+        xg = x.detach().clone().requires_grad_(True)
+        e = intrinsic_forward(sd, t, xg, cond, pre=pre, backbone="ConcatenateMLP")
+        g = torch.autograd.grad(e.sum(), xg)[0]
+    return (scale * g).detach()
+
+
+def guided_score(sd, model_type, path, t, x, cond, scale):
+    """score_function_with_energy_guidance, energy_conditional_diffusion_model.py:1109-1133."""
+    net = intrinsic_forward(sd, t, x, cond)
+    return score_head(model_type, path, net, t, x) + energy_guidance(sd, t, x, cond, scale)
+
+
+# ----------------------------------------------------------------------------- integrators
+def euler_ode(drift, x0, t_span):
+    """Fixed-grid explicit Euler on exactly the caller's grid (torchdyn ``odeint(..,'euler')`` /
+    torchdiffeq ``method='euler'`` as called from numerical_solvers/ode_solver.py:91-100,176-184);
+    ``t`` reaches the drift repeated to (B,) (ode_solver.py:170-174).  Returns (T, B, D).
+    STEPPING PARITY UNPINNED (third-party, see module docstring)."""
+    traj = [x0]
+    x = x0
+    for k in range(len(t_span) - 1):
+        tk = t_span[k].repeat(x.shape[0])
+        x = x + (t_span[k + 1] - t_span[k]) * drift(tk, x)
+        traj.append(x)
+    return torch.stack(traj)
+
+
+def euler_maruyama(drift, diffusion, x0, t_span, dt, increments, repeat_t=True):
+    """torchsde ``sdeint(method='euler', dt=dt)`` as called from numerical_solvers/sde_solver.py:129-140:
+    advance t <- min(t + dt, t_end) from t_span[0], diagonal Ito ``y += f dt + g dW``, outputs
+    linearly interpolated at t_span; ``increments[k]`` is the k-th Brownian increment consumed.
+    STEPPING PARITY UNPINNED."""
+    dt = torch.as_tensor(dt, dtype=t_span.dtype)
+    curr_t, curr_y = t_span[0], x0
+    prev_t, prev_y = curr_t, curr_y
+    ys = [x0]
+    k = 0
+    for out_t in t_span[1:]:
+        while curr_t < out_t:
+            next_t = torch.minimum(curr_t + dt, t_span[-1])
+            prev_t, prev_y = curr_t, curr_y
+            tt = curr_t.repeat(x0.shape[0]) if repeat_t else curr_t
+            curr_y = curr_y + drift(tt, curr_y) * (next_t - curr_t) + diffusion(tt, curr_y) * increments[k]
+            k += 1
+            curr_t = next_t
+        if curr_t == out_t or prev_t == curr_t:
+            ys.append(curr_y)
+        else:
+            w = (out_t - prev_t) / (curr_t - prev_t)
+            ys.append(prev_y + w * (curr_y - prev_y))
+    return torch.stack(ys)
+
+
+# ----------------------------------------------------------------------------- sampling front-end
+def _expand_batch(batch_size, x_0, cond):
+    """Batch bookkeeping of sample_forward_process, diffusion_model/diffusion_model.py:170-234."""
+    if batch_size is None:
+        extra = (1,)
+    elif isinstance(batch_size, int):
+        extra = (batch_size,)
+    else:
+        extra = tuple(int(b) for b in batch_size)
+    if x_0 is not None:
+        n = x_0.shape[0]
+    elif cond is not None:
+        n = cond.shape[0]
+    else:
+        n = 1
+    return extra, n
+
+
+def _reshape_out(data, batch_size, extra, n, x_size, x_0, cond):
+    """diffusion_model.py:369-416: reshape (T, B*N, D) -> (T, *B, N, D) and squeeze (this reads
+    rows laid out n*B+b as b*N+n -- reproduced as written)."""
+    xs = (x_size,) if isinstance(x_size, int) else tuple(x_size)
+    data = data.reshape(-1, *extra, n, *xs)
+    if batch_size is None:
+        data = data.squeeze(1).squeeze(1) if (x_0 is None and cond is None) else data.squeeze(1)
+    elif x_0 is None and cond is None:
+        data = data.squeeze(1 + len(extra))
+    return data
+
+
+def sample_forward_process(sd, cfg, kind, t_span, batch_size=None, x_0=None, condition=None,
+                           x_T=None, guidance_scale=1.0, solver="ODESolver", dt=None, increments=None):
+    """DiffusionModel / EnergyConditionalDiffusionModel / IndependentConditionalFlowModel
+    ``sample_forward_process`` (diffusion_model.py:135-470, energy_conditional_diffusion_model.py:257-615,
+    conditional_flow_model/independent_conditional_flow_model.py:170-450).  ``x_T`` replaces the
+    draw from ``gaussian_generator`` (shape (prod(B)*N, D)) so runs are reproducible."""
+    extra, n = _expand_batch(batch_size, x_0, condition)
+    rep = int(math.prod(extra))
+    x = x_T if x_0 is None else torch.repeat_interleave(x_0, rep, dim=0)
+    cond = None if condition is None else torch.repeat_interleave(condition, rep, dim=0)
+    mt = cfg["model"]["type"]
+    if kind == "icfm":
+        data = euler_ode(lambda t, y: intrinsic_forward(sd, t, y, cond), x, t_span)
+    else:
+        path = Path(cfg["path"])
+        if kind == "energy":
+            fn = lambda t, y: guided_score(sd, mt, path, t, y, cond, guidance_scale)  # noqa: E731
+            ftype = "score_function"
+        else:
+            fn = lambda t, y: intrinsic_forward(sd, t, y, cond)  # noqa: E731
+            ftype = mt
+        if solver == "ODESolver":
+            data = euler_ode(lambda t, y: reverse_ode_drift(ftype, path, fn, t, y), x, t_span)
+        else:
+            rpath = Path(cfg["reverse_path"])
+            data = euler_maruyama(lambda t, y: reverse_sde_drift(ftype, path, rpath, fn, t, y),
+                                  lambda t, y: reverse_sde_diffusion(rpath, t, y),
+                                  x, t_span, dt, increments)
+    return _reshape_out(data, batch_size, extra, n, cfg["x_size"], x_0, condition)
+
+
+# ----------------------------------------------------------------------------- losses
+def _row_loss(pred, target, average):
+    per_row = torch.sum(0.5 * (pred - target) ** 2, dim=1)
+    return per_row.mean() if average else per_row
+
+
+def score_matching_loss(model_type, path, net_fn, x, t, eps, average=True):
+    """ScoreFunction.score_matching_loss, model_functions/score_function.py:192-251, with the
+    random draws (t first, then eps) passed in explicitly."""
+    std, scale = _b(path.std(t), x), _b(path.scale(t), x)
+    x_t = scale * x + std * eps
+    net = net_fn(t, x_t)
+    if model_type == "noise_function":
+        pred = net
+    elif model_type == "score_function":
+        pred = net * std
+    elif model_type == "velocity_function":
+        pred = (net - _b(path.f(t), x) * x_t) * 2.0 * std / _b(path.g2(t), x)
+    elif model_type == "data_prediction_function":
+        pred = (x_t - scale * net) / std
+    else:
+        raise NotImplementedError(model_type)
+    return _row_loss(pred, eps, average)
+
+
+def flow_matching_loss(model_type, path, net_fn, x, t, eps, average=True):
+    """VelocityFunction.flow_matching_loss, model_functions/velocity_function.py:131-214."""
+    std, scale = _b(path.std(t), x), _b(path.scale(t), x)
+    x_t = scale * x + std * eps
+    net = net_fn(t, x_t)
+    fx = _b(path.f(t), x) * x_t
+    g2 = _b(path.g2(t), x)
+    if model_type == "noise_function":
+        pred = fx + 0.5 * g2 * net / std
+    elif model_type == "score_function":
+        pred = fx - 0.5 * g2 * net
+    elif model_type == "velocity_function":
+        pred = net
+    elif model_type == "data_prediction_function":
+        D = 0.5 * g2 / _b(path.cov(t), x)
+        pred = (_b(path.f(t), x) + D) * x_t - D * scale * net
+    else:
+        raise NotImplementedError(model_type)
+    target = _b(path.d_scale(t), x) * x + _b(path.d_std(t), x) * eps  # diffusion_process.py:405-417
+    return _row_loss(pred, target, average)
+
+
+def icfm_flow_matching_loss(net_fn, x0, x1, t, eps, sigma, average=True):
+    """VelocityFunction.flow_matching_loss_icfm, velocity_function.py:289-296 with
+    StochasticProcess.direct_sample / velocity, generative_models/stochastic_process.py:26-129."""
+    tb = _b(t, x0)
+    x_t = x0 * (1.0 - tb) + x1 * tb + sigma * eps
+    return _row_loss(net_fn(t, x_t), x1 - x0, average)
