@@ -1,0 +1,300 @@
+// C ABI of the MI355X generative-policy hot path (declarations + contract: include/grlhip.h).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "plan.hpp"
+using namespace grlhip;
+
+#include "engine_f32.hip.inc"
+#include "engine_bf16.hip.inc"
+
+struct grlhip_plan {
+  Plan* p;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) return fail(GRLHIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+int device_cus() {
+  static int cus = -1;
+  if (cus < 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      cus = v;
+    else
+      cus = 256;
+  }
+  return cus;
+}
+
+// fp32 engine launch geometry: 4 waves (=4 row tiles in flight) per block, <= 4 blocks per CU
+int f32_blocks(int64_t rows) {
+  const int64_t ntiles = (rows + 31) / 32;
+  const int64_t want = (ntiles + 3) / 4;
+  const int64_t cap = (int64_t)device_cus() * 4;
+  return (int)std::max<int64_t>(1, std::min(want, cap));
+}
+
+NetArgs net_args(const Plan* p, const void* packed, bool grad_program, int slab_base) {
+  NetArgs n{};
+  n.w = (const float*)packed;
+  n.ops = (const Op*)(grad_program ? p->d_grad : p->d_fwd);
+  n.n_ops = (int32_t)(grad_program ? p->grad.size() : p->fwd.size());
+  n.temb_off = p->temb_off; n.x_off = p->x_off; n.c_off = p->c_off;
+  n.out_off = grad_program ? p->gradx_off : p->out_off;
+  n.t_dim = p->desc.t_dim; n.x_dim = p->desc.x_dim; n.c_dim = p->desc.cond_dim;
+  n.out_dim = grad_program ? p->desc.x_dim : p->desc.out_dim;
+  n.fourier_off = (int32_t)p->fourier_off;
+  n.slab_base = slab_base;
+  return n;
+}
+
+int upload(const std::vector<Op>& ops, void** d) {
+  *d = nullptr;
+  if (ops.empty()) return 0;
+  HIP_TRY(hipMalloc(d, ops.size() * sizeof(Op)));
+  HIP_TRY(hipMemcpy(*d, ops.data(), ops.size() * sizeof(Op), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int check_ready(const grlhip_plan* plan, const void* packed) {
+  if (!plan || !plan->p) return fail(GRLHIP_ERR_INVALID, "null plan");
+  if (!packed) return fail(GRLHIP_ERR_INVALID, "null packed weight image");
+  if (!plan->p->d_fwd) return fail(GRLHIP_ERR_HIP, "plan was created without a usable HIP device");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* grlhip_last_error(void) { return g_err.c_str(); }
+
+int grlhip_device_available(void) {
+  int n = 0;
+  return (hipGetDeviceCount(&n) == hipSuccess && n > 0) ? 1 : 0;
+}
+
+int grlhip_plan_create(const grlhip_net_desc* net, grlhip_plan** out_plan) {
+  if (!net || !out_plan) return fail(GRLHIP_ERR_INVALID, "null argument");
+  std::string err;
+  Plan* p = build_plan(*net, err);
+  if (!p) return fail(GRLHIP_ERR_INVALID, err);
+  if (grlhip_device_available()) {
+    int rc = upload(p->fwd, &p->d_fwd);
+    if (rc == 0) rc = upload(p->grad, &p->d_grad);
+    if (rc != 0) { delete p; return rc; }
+  }
+  *out_plan = new grlhip_plan{p};
+  return 0;
+}
+
+void grlhip_plan_destroy(grlhip_plan* plan) {
+  if (!plan) return;
+  if (plan->p) {
+    if (plan->p->d_fwd) (void)hipFree(plan->p->d_fwd);
+    if (plan->p->d_grad) (void)hipFree(plan->p->d_grad);
+    delete plan->p;
+  }
+  delete plan;
+}
+
+int grlhip_plan_num_params(const grlhip_plan* plan) { return plan && plan->p ? (int)plan->p->params.size() : 0; }
+
+int grlhip_plan_param_info(const grlhip_plan* plan, int index, char* name_buf, size_t name_buf_len,
+                           int32_t* rows, int32_t* cols) {
+  if (!plan || !plan->p || index < 0 || index >= (int)plan->p->params.size())
+    return fail(GRLHIP_ERR_INVALID, "parameter index out of range");
+  const ParamInfo& pi = plan->p->params[index];
+  if (name_buf && name_buf_len) {
+    std::strncpy(name_buf, pi.name.c_str(), name_buf_len - 1);
+    name_buf[name_buf_len - 1] = 0;
+  }
+  if (rows) *rows = pi.rows;
+  if (cols) *cols = pi.cols;
+  return 0;
+}
+
+int64_t grlhip_grad_numel(const grlhip_plan* plan) { return plan && plan->p ? plan->p->grad_numel : 0; }
+int64_t grlhip_grad_offset(const grlhip_plan* plan, int index) {
+  if (!plan || !plan->p || index < 0 || index >= (int)plan->p->params.size()) return -1;
+  return plan->p->params[index].grad_off;
+}
+
+size_t grlhip_packed_bytes(const grlhip_plan* plan, int dtype) {
+  if (!plan || !plan->p) return 0;
+  if (dtype == GRLHIP_F32) return (size_t)plan->p->packed_floats * sizeof(float);
+  if (dtype == GRLHIP_BF16) return bf16_packed_bytes(plan->p);
+  return 0;
+}
+
+int grlhip_pack_weights(const grlhip_plan* plan, const void* const* params, int n, int dtype, void* packed,
+                        void* stream) {
+  if (!plan || !plan->p || !params || !packed) return fail(GRLHIP_ERR_INVALID, "null argument");
+  const Plan* p = plan->p;
+  if (n != (int)p->params.size()) return fail(GRLHIP_ERR_INVALID, "expected " + std::to_string(p->params.size()) + " parameters");
+  for (int i = 0; i < n; ++i)
+    if (!params[i]) return fail(GRLHIP_ERR_INVALID, "null parameter pointer: " + p->params[i].name);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == GRLHIP_BF16) return bf16_pack(p, params, packed, st, g_err);
+  if (dtype != GRLHIP_F32) return fail(GRLHIP_ERR_UNSUPPORTED, "unknown dtype");
+  float* dst = (float*)packed;
+  for (const LinearDesc& l : p->linears) {
+    PackArgs a{};
+    a.src_w = (const float*)params[l.p_w];
+    a.src_b = l.p_b >= 0 ? (const float*)params[l.p_b] : nullptr;
+    a.dst = dst; a.N = l.N; a.K = l.K; a.Npad = l.Npad; a.Kpad = l.Kpad;
+    a.col0 = l.col0; a.src_cols = l.src_cols; a.transposed = l.transposed;
+    a.w_off = l.w_off; a.b_off = l.b_off;
+    const int64_t total = (int64_t)l.Npad * l.Kpad + l.Npad;
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_pack_f32, dim3(blocks), dim3(256), 0, st, a);
+  }
+  const int half = p->desc.t_dim / 2;
+  hipLaunchKernelGGL(k_copy_pad_f32, dim3(1), dim3(64), 0, st, (const float*)params[0], dst + p->fourier_off, half,
+                     (int)(p->packed_floats - p->fourier_off));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+size_t grlhip_workspace_bytes(const grlhip_plan* plan, const grlhip_plan* guidance, int64_t rows, int dtype) {
+  if (!plan || !plan->p || rows <= 0) return 0;
+  if (dtype == GRLHIP_BF16) return bf16_workspace_bytes(plan->p, guidance ? guidance->p : nullptr, rows);
+  const int64_t feats = plan->p->slab_features + (guidance && guidance->p ? guidance->p->slab_features : 0);
+  return (size_t)f32_blocks(rows) * 4 * feats * 32 * sizeof(float);
+}
+
+int grlhip_net_forward(const grlhip_plan* plan, const void* packed, int dtype, const float* t, const float* x,
+                       const float* cond, float* out, int64_t rows, void* workspace, size_t workspace_bytes,
+                       void* stream) {
+  if (int rc = check_ready(plan, packed)) return rc;
+  const Plan* p = plan->p;
+  if (rows <= 0) return 0;
+  if (!t || !x || !out) return fail(GRLHIP_ERR_INVALID, "null t/x/out");
+  if ((p->desc.cond_dim > 0) != (cond != nullptr))
+    return fail(GRLHIP_ERR_INVALID, "condition pointer does not match the plan's cond_dim");
+  if (dtype != GRLHIP_F32) return fail(GRLHIP_ERR_UNSUPPORTED, "net_forward: only GRLHIP_F32 is implemented");
+  const size_t need = grlhip_workspace_bytes(plan, nullptr, rows, dtype);
+  if (!workspace || workspace_bytes < need) return fail(GRLHIP_ERR_WORKSPACE, "workspace too small: need " + std::to_string(need));
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(workspace, 0, need, st));
+  ForwardArgs a{};
+  a.net = net_args(p, packed, false, 0);
+  a.t = t; a.x = x; a.cond = cond; a.out = out; a.rows = rows; a.workspace = (float*)workspace;
+  a.slab_features = p->slab_features; a.mode = 0; a.scale = 1.f;
+  hipLaunchKernelGGL(k_forward_f32, dim3(f32_blocks(rows)), dim3(256), 0, st, a);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int grlhip_energy_grad(const grlhip_plan* plan, const void* packed, int dtype, const float* t, const float* x,
+                       const float* cond, float scale, float* grad, int64_t rows, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+  if (int rc = check_ready(plan, packed)) return rc;
+  const Plan* p = plan->p;
+  if (p->desc.kind != GRLHIP_NET_CONCAT_MLP) return fail(GRLHIP_ERR_INVALID, "energy_grad needs a CONCAT_MLP plan");
+  if (rows <= 0) return 0;
+  if (!t || !x || !grad) return fail(GRLHIP_ERR_INVALID, "null t/x/grad");
+  if ((p->desc.cond_dim > 0) != (cond != nullptr))
+    return fail(GRLHIP_ERR_INVALID, "condition pointer does not match the plan's cond_dim");
+  if (dtype != GRLHIP_F32) return fail(GRLHIP_ERR_UNSUPPORTED, "energy_grad: only GRLHIP_F32 is implemented");
+  const size_t need = grlhip_workspace_bytes(plan, nullptr, rows, dtype);
+  if (!workspace || workspace_bytes < need) return fail(GRLHIP_ERR_WORKSPACE, "workspace too small: need " + std::to_string(need));
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(workspace, 0, need, st));
+  ForwardArgs a{};
+  a.net = net_args(p, packed, true, 0);
+  a.t = t; a.x = x; a.cond = cond; a.out = grad; a.rows = rows; a.workspace = (float*)workspace;
+  a.slab_features = p->slab_features; a.mode = 1; a.scale = scale;
+  hipLaunchKernelGGL(k_forward_f32, dim3(f32_blocks(rows)), dim3(256), 0, st, a);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+static int sample_common(const grlhip_plan* plan, const void* packed, int dtype, const grlhip_plan* guidance,
+                         const void* guidance_packed, const float* x0, const float* cond, const float* coef,
+                         const float* dW, int32_t n_steps, int64_t rows, float* out_final, float* out_traj,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_ready(plan, packed)) return rc;
+  const Plan* p = plan->p;
+  if (p->desc.kind != GRLHIP_NET_RESNET) return fail(GRLHIP_ERR_INVALID, "sampling needs a RESNET plan");
+  if (p->desc.out_dim != p->desc.x_dim) return fail(GRLHIP_ERR_INVALID, "sampling needs out_dim == x_dim");
+  if (rows <= 0) return 0;
+  if (n_steps < 0) return fail(GRLHIP_ERR_INVALID, "n_steps < 0");
+  if (!x0 || !out_final || (n_steps > 0 && !coef)) return fail(GRLHIP_ERR_INVALID, "null x0/out_final/coef");
+  if ((p->desc.cond_dim > 0) != (cond != nullptr))
+    return fail(GRLHIP_ERR_INVALID, "condition pointer does not match the plan's cond_dim");
+  const Plan* g = nullptr;
+  if (guidance) {
+    if (int rc = check_ready(guidance, guidance_packed)) return rc;
+    g = guidance->p;
+    if (g->desc.kind != GRLHIP_NET_CONCAT_MLP || g->desc.x_dim != p->desc.x_dim || g->desc.cond_dim != p->desc.cond_dim)
+      return fail(GRLHIP_ERR_INVALID, "guidance plan must be a CONCAT_MLP over the same x/cond dims");
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == GRLHIP_BF16)
+    return bf16_sample(p, packed, g, guidance_packed, x0, cond, coef, dW, n_steps, rows, out_final, out_traj,
+                       workspace, workspace_bytes, st, g_err);
+  if (dtype != GRLHIP_F32) return fail(GRLHIP_ERR_UNSUPPORTED, "unknown dtype");
+  const size_t need = grlhip_workspace_bytes(plan, guidance, rows, dtype);
+  if (!workspace || workspace_bytes < need) return fail(GRLHIP_ERR_WORKSPACE, "workspace too small: need " + std::to_string(need));
+  HIP_TRY(hipMemsetAsync(workspace, 0, need, st));
+  SampleArgs a{};
+  a.net = net_args(p, packed, false, 0);
+  if (g) a.gnet = net_args(g, guidance_packed, true, p->slab_features);
+  a.x0 = x0; a.cond = cond; a.coef = coef; a.dW = dW; a.out_final = out_final; a.out_traj = out_traj;
+  a.rows = rows; a.n_steps = n_steps; a.slab_features = p->slab_features + (g ? g->slab_features : 0);
+  a.workspace = (float*)workspace;
+  hipLaunchKernelGGL(k_sample_f32, dim3(f32_blocks(rows)), dim3(256), 0, st, a);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int grlhip_sample_ode(const grlhip_plan* plan, const void* packed, int dtype, const grlhip_plan* guidance,
+                      const void* guidance_packed, const float* x0, const float* cond, const float* coef,
+                      int32_t n_steps, int64_t rows, float* out_final, float* out_traj, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+  return sample_common(plan, packed, dtype, guidance, guidance_packed, x0, cond, coef, nullptr, n_steps, rows,
+                       out_final, out_traj, workspace, workspace_bytes, stream);
+}
+
+int grlhip_sample_sde(const grlhip_plan* plan, const void* packed, int dtype, const grlhip_plan* guidance,
+                      const void* guidance_packed, const float* x0, const float* cond, const float* coef,
+                      const float* dW, int32_t n_steps, int64_t rows, float* out_final, float* out_traj,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+  if (!dW && n_steps > 0) return fail(GRLHIP_ERR_INVALID, "sample_sde needs the Brownian increment buffer dW");
+  return sample_common(plan, packed, dtype, guidance, guidance_packed, x0, cond, coef, dW, n_steps, rows,
+                       out_final, out_traj, workspace, workspace_bytes, stream);
+}
+
+size_t grlhip_loss_workspace_bytes(const grlhip_plan* plan, int64_t rows, int dtype) {
+  (void)plan; (void)rows; (void)dtype;
+  return 0;
+}
+
+int grlhip_loss_fwd_bwd(const grlhip_plan* plan, const void* packed, int dtype, const float* t, const float* x_t,
+                        const float* cond, const float* alpha, const float* beta, const float* target,
+                        const float* row_weight, float* loss_rows, float* grad_flat, int64_t rows, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+  (void)plan; (void)packed; (void)dtype; (void)t; (void)x_t; (void)cond; (void)alpha; (void)beta; (void)target;
+  (void)row_weight; (void)loss_rows; (void)grad_flat; (void)rows; (void)workspace; (void)workspace_bytes; (void)stream;
+  return fail(GRLHIP_ERR_UNSUPPORTED, "loss_fwd_bwd: not built yet");
+}
+
+}  // extern "C"

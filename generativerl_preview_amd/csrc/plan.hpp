@@ -1,0 +1,67 @@
+// Host-side plan: parameter list, op program, activation-slab layout and packed-weight layout
+// for one network (TemporalSpatialResidualNet or ConcatenateMLP).  Pure C++ (no HIP types) so the
+// layout logic can be unit-tested on the CPU.
+//
+// Activation slab (fp32 engine): every wave owns 32 batch rows; a buffer of F features is stored
+// feature-major as slab[(off + f) * 32 + row].  Offsets below are in FEATURES.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/grlhip.h"
+
+namespace grlhip {
+
+enum OpType : int32_t {
+  OP_LINEAR = 0,         // out[n] = act(sum_k W[n][k] in[k] + b[n]) (+ slab[add + n])
+  OP_SILU = 1,           // out[n] = silu(in[n])
+  OP_COPY = 2,           // out[n] = in[n]
+  OP_SILU_BWD = 3,       // out[n] = slab[add + n] * silu'(in[n])
+  OP_SILU_BWD_CONST = 4  // out[n] = wts[w + n] * silu'(in[n])
+};
+enum OpFlags : int32_t { F_SILU_OUT = 1, F_SAVE_PRE = 2 };
+
+struct Op {
+  int32_t type, K, N, w, b, in, out, add, flags, pre;  // pre: where z (pre-activation) is kept (F_SAVE_PRE)
+  int32_t lin;                                         // index into linears (OP_LINEAR), else -1
+  int32_t pad;
+};
+
+struct ParamInfo {
+  std::string name;
+  int32_t rows, cols;  // cols == 0: vector
+  int64_t grad_off;    // offset in the flat gradient buffer
+};
+
+// One packed matrix: M[n][k] (n < N, k < K) gathered from parameter p_w as
+//   transposed ? P[k * src_cols + col0 + n] : P[n * src_cols + col0 + k]
+struct LinearDesc {
+  int32_t N, K, Npad, Kpad;
+  int32_t p_w, p_b;  // parameter indices (p_b = -1: zero bias)
+  int32_t col0, src_cols, transposed;
+  int64_t w_off, b_off;    // fp32 image, in floats
+  int64_t w_off16, b_off16;  // bf16 image: weights offset in bf16 elements, bias offset in floats of the f32 tail
+};
+
+struct Plan {
+  grlhip_net_desc desc;
+  std::vector<ParamInfo> params;
+  std::vector<LinearDesc> linears;
+  std::vector<Op> fwd;       // forward program
+  std::vector<Op> grad;      // CONCAT_MLP only: forward (pre-activations) + backward to x
+  int32_t slab_features = 0;
+  int32_t temb_off = 0, x_off = 0, c_off = 0, out_off = 0, gradx_off = 0;
+  int64_t fourier_off = 0;   // offset of W (t_dim/2 floats) in the fp32 image
+  int64_t packed_floats = 0; // size of the fp32 image
+  int64_t grad_numel = 0;
+  // device copies of the programs (uploaded at creation)
+  void* d_fwd = nullptr;
+  void* d_grad = nullptr;
+  std::string error;
+};
+
+// Returns nullptr and fills err on invalid descriptors.
+Plan* build_plan(const grlhip_net_desc& d, std::string& err);
+
+}  // namespace grlhip

@@ -1,0 +1,136 @@
+"""Thin object layer over the C ABI: plans, packed weight images, workspaces."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _f32c(t, name, shape=None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise L.GrlHipError("%s must live on a HIP device (got %s): the hot path has no CPU fallback" % (name, t.device))
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    t = t.contiguous()
+    if shape is not None:
+        assert tuple(t.shape) == tuple(shape), "%s: expected shape %s, got %s" % (name, tuple(shape), tuple(t.shape))
+    return t
+
+
+class NetPlan:
+    """One network description -> plan handle (grlhip_plan_create)."""
+
+    def __init__(self, kind, x_dim, out_dim, cond_dim, t_dim, cond_hidden, t_cond_hidden, hidden):
+        d = L.NetDesc()
+        d.kind, d.x_dim, d.out_dim, d.cond_dim, d.t_dim = kind, x_dim, out_dim, cond_dim or 0, t_dim
+        d.cond_hidden, d.t_cond_hidden, d.n_hidden = cond_hidden or 0, t_cond_hidden or 0, len(hidden)
+        if len(hidden) > L.MAX_HIDDEN:
+            raise ValueError("at most %d hidden sizes are supported" % L.MAX_HIDDEN)
+        for i, h in enumerate(hidden):
+            d.hidden[i] = int(h)
+        self.desc = d
+        self.kind, self.x_dim, self.out_dim, self.cond_dim = kind, x_dim, out_dim, cond_dim or 0
+        h = ctypes.c_void_p()
+        L.check(L.lib().grlhip_plan_create(ctypes.byref(d), ctypes.byref(h)))
+        self.handle = h
+        self._ws = {}
+        n = L.lib().grlhip_plan_num_params(h)
+        self.params = []
+        buf = ctypes.create_string_buffer(256)
+        for i in range(n):
+            r, c = ctypes.c_int32(), ctypes.c_int32()
+            L.check(L.lib().grlhip_plan_param_info(h, i, buf, 256, ctypes.byref(r), ctypes.byref(c)))
+            self.params.append((buf.value.decode(), (r.value, c.value) if c.value else (r.value,)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                L.lib().grlhip_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def packed_bytes(self, dtype=L.F32):
+        return L.lib().grlhip_packed_bytes(self.handle, dtype)
+
+    def pack(self, named_tensors, dtype=L.F32):
+        """named_tensors: mapping plan-relative name -> fp32 device tensor."""
+        ts = []
+        for name, shape in self.params:
+            t = _f32c(named_tensors[name], name)
+            if tuple(t.shape) != tuple(shape):
+                raise ValueError("parameter %s: expected %s, got %s" % (name, shape, tuple(t.shape)))
+            ts.append(t)
+        dev = ts[0].device
+        packed = torch.empty(self.packed_bytes(dtype), dtype=torch.uint8, device=dev)
+        arr = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        with torch.cuda.device(dev):
+            L.check(L.lib().grlhip_pack_weights(self.handle, arr, len(ts), dtype, _ptr(packed), _stream(dev)))
+        return packed
+
+    def workspace(self, rows, device, guidance=None, dtype=L.F32):
+        need = L.lib().grlhip_workspace_bytes(self.handle, guidance.handle if guidance else None, rows, dtype)
+        key = (str(device), dtype)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(max(need, 256), dtype=torch.uint8, device=device)
+            self._ws[key] = ws
+        return ws
+
+    def forward(self, packed, t, x, cond, dtype=L.F32):
+        rows = x.shape[0]
+        dev = x.device
+        t, x, cond = _f32c(t, "t", (rows,)), _f32c(x, "x", (rows, self.x_dim)), _f32c(cond, "condition")
+        out = torch.empty(rows, self.out_dim, dtype=torch.float32, device=dev)
+        ws = self.workspace(rows, dev, None, dtype)
+        with torch.cuda.device(dev):
+            L.check(L.lib().grlhip_net_forward(self.handle, _ptr(packed), dtype, _ptr(t), _ptr(x), _ptr(cond),
+                                               _ptr(out), rows, _ptr(ws), ws.numel(), _stream(dev)))
+        return out
+
+    def energy_grad(self, packed, t, x, cond, scale, dtype=L.F32):
+        rows = x.shape[0]
+        dev = x.device
+        t, x, cond = _f32c(t, "t", (rows,)), _f32c(x, "x", (rows, self.x_dim)), _f32c(cond, "condition")
+        out = torch.empty(rows, self.x_dim, dtype=torch.float32, device=dev)
+        ws = self.workspace(rows, dev, None, dtype)
+        with torch.cuda.device(dev):
+            L.check(L.lib().grlhip_energy_grad(self.handle, _ptr(packed), dtype, _ptr(t), _ptr(x), _ptr(cond),
+                                               float(scale), _ptr(out), rows, _ptr(ws), ws.numel(), _stream(dev)))
+        return out
+
+    def sample(self, packed, x0, cond, coef, dW=None, guidance=None, guidance_packed=None, trajectory_slots=0,
+               dtype=L.F32):
+        """coef: (n_steps, 8) fp32 table (see include/grlhip.h).  Returns (final, traj|None)."""
+        rows, D = x0.shape
+        dev = x0.device
+        x0, cond = _f32c(x0, "x_0", (rows, self.x_dim)), _f32c(cond, "condition")
+        coef = _f32c(coef.to(dev), "coef")
+        n_steps = coef.shape[0]
+        assert coef.dim() == 2 and coef.shape[1] == L.COEF_STRIDE
+        dW = _f32c(dW, "noise increments", (n_steps, rows, D)) if dW is not None else None
+        final = torch.empty(rows, D, dtype=torch.float32, device=dev)
+        traj = torch.empty(trajectory_slots, rows, D, dtype=torch.float32, device=dev) if trajectory_slots else None
+        ws = self.workspace(rows, dev, guidance, dtype)
+        g_h = guidance.handle if guidance is not None else None
+        with torch.cuda.device(dev):
+            if dW is None:
+                L.check(L.lib().grlhip_sample_ode(self.handle, _ptr(packed), dtype, g_h, _ptr(guidance_packed),
+                                                  _ptr(x0), _ptr(cond), _ptr(coef), n_steps, rows, _ptr(final),
+                                                  _ptr(traj), _ptr(ws), ws.numel(), _stream(dev)))
+            else:
+                L.check(L.lib().grlhip_sample_sde(self.handle, _ptr(packed), dtype, g_h, _ptr(guidance_packed),
+                                                  _ptr(x0), _ptr(cond), _ptr(coef), _ptr(dW), n_steps, rows,
+                                                  _ptr(final), _ptr(traj), _ptr(ws), ws.numel(), _stream(dev)))
+        return final, traj

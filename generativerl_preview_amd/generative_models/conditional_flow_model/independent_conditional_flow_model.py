@@ -1,0 +1,78 @@
+"""IndependentConditionalFlowModel (ICFM), grl/generative_models/conditional_flow_model/
+independent_conditional_flow_model.py:27-897: velocity net, Euler ODE sampling with
+drift = model(t, x, c) on time 0 -> 1, and flow_matching_loss(x0, x1, condition)."""
+import torch
+import torch.nn as nn
+
+from ...config import as_config
+from ...numerical_methods.numerical_solvers import get_solver
+from ...numerical_methods.numerical_solvers.ode_solver import ODESolver
+from ...numerical_methods.probability_path import ConditionalProbabilityPath
+from ..fused import FusedDrift
+from ..intrinsic_model import IntrinsicModel
+from ..model_functions.losses import fused_loss, prepare_icfm
+from ..random_generator import gaussian_random_variable
+from ..sampling import expand_inputs, reshape_output
+from ..stochastic_process import StochasticProcess
+
+
+class IndependentConditionalFlowModel(nn.Module):
+    def __init__(self, config) -> None:
+        super().__init__()
+        config = as_config(config)
+        self.config = config
+        self.x_size = config.x_size
+        self.device = config.device
+        self.gaussian_generator = gaussian_random_variable(config.x_size, config.device,
+                                                           config.use_tree_tensor if hasattr(config, "use_tree_tensor") else False)
+        self.path = ConditionalProbabilityPath(config.path)
+        if hasattr(config, "reverse_path"):
+            self.reverse_path = ConditionalProbabilityPath(config.reverse_path)
+        else:
+            self.reverse_path = None
+        self.model_type = config.model.type
+        assert self.model_type in ["velocity_function"], "Unknown type of model {}".format(self.model_type)
+        self.model = IntrinsicModel(config.model.args)
+        self.stochastic_process = StochasticProcess(self.path)
+        if hasattr(config, "solver"):
+            self.solver = get_solver(config.solver.type)(**config.solver.args)
+
+    def get_type(self):
+        return "IndependentConditionalFlowModel"
+
+    def sample(self, t_span=None, batch_size=None, x_0=None, condition=None, with_grad: bool = False,
+               solver_config=None):
+        """:80-119"""
+        return self.sample_forward_process(t_span=t_span, batch_size=batch_size, x_0=x_0, condition=condition,
+                                           with_grad=with_grad, solver_config=solver_config, _final_only=True)
+
+    def sample_forward_process(self, t_span=None, batch_size=None, x_0=None, condition=None,
+                               with_grad: bool = False, solver_config=None, _final_only=False):
+        """:170-450"""
+        if with_grad:
+            raise NotImplementedError("differentiable sampling (with_grad=True) is not part of the fused hot path yet")
+        if t_span is not None:
+            t_span = t_span.to(self.device)
+        extra, n, x, condition = expand_inputs(self, batch_size, x_0, condition)
+        if solver_config is not None:
+            solver_config = as_config(solver_config)
+            solver = get_solver(solver_config.type)(**solver_config.args)
+        else:
+            assert hasattr(self, "solver"), "solver must be specified in config or solver_config"
+            solver = self.solver
+        if not isinstance(solver, ODESolver):
+            raise NotImplementedError("Not implemented")  # :283-284,342-343
+        drift = FusedDrift("icfm", self.model, self.model_type, condition=condition)
+        data = solver.integrate(drift=drift, x0=x, t_span=t_span, return_trajectory=not _final_only)
+        if _final_only:
+            data = data.unsqueeze(0)
+        data = reshape_output(self, data, batch_size, extra, n, x_0, condition)
+        return data[-1] if _final_only else data
+
+    def flow_matching_loss(self, x0, x1, condition=None, average: bool = True, sum_all_elements: bool = True,
+                           t=None, noise=None):
+        """:678-697 -> velocity_function.py:220-302"""
+        if not sum_all_elements:
+            raise NotImplementedError("element-wise (sum_all_elements=False) losses are not fused")
+        t, x_t, alpha, beta, target = prepare_icfm(self.stochastic_process, x0, x1, t, noise)
+        return fused_loss(self.model, t, x_t, condition, alpha, beta, target, average)

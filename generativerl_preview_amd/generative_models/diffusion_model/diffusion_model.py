@@ -1,0 +1,106 @@
+"""DiffusionModel (grl/generative_models/diffusion_model/diffusion_model.py:24-1233): config schema,
+``sample`` / ``sample_forward_process`` shape contract and the two training losses, running on the
+fused HIP integrator / fused loss kernels."""
+from typing import List, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from ...config import as_config
+from ...numerical_methods.numerical_solvers import get_solver
+from ...numerical_methods.numerical_solvers.ode_solver import ODESolver
+from ...numerical_methods.numerical_solvers.sde_solver import SDESolver
+from ...numerical_methods.probability_path import GaussianConditionalProbabilityPath
+from ..diffusion_process import DiffusionProcess
+from ..intrinsic_model import IntrinsicModel
+from ..model_functions.losses import fused_loss, prepare_flow_matching, prepare_score_matching
+from ..random_generator import gaussian_random_variable
+from ..sampling import expand_inputs, reshape_output
+
+MODEL_TYPES = ["score_function", "data_prediction_function", "velocity_function", "noise_function"]
+
+
+class DiffusionModel(nn.Module):
+    def __init__(self, config) -> None:
+        super().__init__()
+        config = as_config(config)
+        self.config = config
+        self.x_size = config.x_size
+        self.device = config.device
+        self.alpha = config.alpha if hasattr(config, "alpha") else 1.0
+        self.gaussian_generator = gaussian_random_variable(config.x_size, config.device,
+                                                           config.use_tree_tensor if hasattr(config, "use_tree_tensor") else False)
+        self.path = GaussianConditionalProbabilityPath(config.path)
+        self.reverse_path = GaussianConditionalProbabilityPath(config.reverse_path) if hasattr(config, "reverse_path") else None
+        self.model_type = config.model.type
+        assert self.model_type in MODEL_TYPES, "Unknown type of model {}".format(self.model_type)
+        self.model = IntrinsicModel(config.model.args)
+        self.diffusion_process = DiffusionProcess(self.path)
+        self.reverse_diffusion_process = DiffusionProcess(self.reverse_path) if self.reverse_path is not None else None
+        if hasattr(config, "solver"):
+            self.solver = get_solver(config.solver.type)(**config.solver.args)
+
+    def get_type(self):
+        return "DiffusionModel"
+
+    # ------------------------------------------------------------------ sampling
+    def sample(self, t_span: torch.Tensor = None, batch_size: Union[torch.Size, int, Tuple[int], List[int]] = None,
+               x_0=None, condition=None, with_grad: bool = False, solver_config=None, **kw):
+        """diffusion_model.py:94-133 -- final state of ``sample_forward_process``."""
+        return self.sample_forward_process(t_span=t_span, batch_size=batch_size, x_0=x_0, condition=condition,
+                                           with_grad=with_grad, solver_config=solver_config,
+                                           _final_only=True, **kw)
+
+    def _function(self, guidance_scale):
+        return self.model, self.model_type
+
+    def sample_forward_process(self, t_span: torch.Tensor = None, batch_size=None, x_0=None, condition=None,
+                               with_grad: bool = False, solver_config=None, noise_increments=None,
+                               _final_only=False, _guidance_scale=None):
+        """diffusion_model.py:135-470.  Returns (T, ...) with the reference's shape rules.
+        ``noise_increments`` (superset) pins the Brownian path of the SDE solver."""
+        if with_grad:
+            raise NotImplementedError("differentiable sampling (with_grad=True) is not part of the fused hot path yet")
+        if t_span is not None:
+            t_span = t_span.to(self.device)
+        extra, n, x, condition = expand_inputs(self, batch_size, x_0, condition)
+        if solver_config is not None:
+            solver_config = as_config(solver_config)
+            solver = get_solver(solver_config.type)(**solver_config.args)
+        else:
+            assert hasattr(self, "solver"), "solver must be specified in config or solver_config"
+            solver = self.solver
+        function, function_type = self._function(_guidance_scale)
+        if isinstance(solver, ODESolver):
+            drift = self.diffusion_process.reverse_ode(function=function, function_type=function_type,
+                                                       condition=condition).drift
+            data = solver.integrate(drift=drift, x0=x, t_span=t_span, return_trajectory=not _final_only)
+        elif isinstance(solver, SDESolver):
+            assert self.reverse_diffusion_process is not None, "reverse_path must be specified in config"
+            sde = self.diffusion_process.reverse_sde(
+                function=function, function_type=function_type, condition=condition,
+                reverse_diffusion_function=self.reverse_diffusion_process.diffusion,
+                reverse_diffusion_squared_function=self.reverse_diffusion_process.diffusion_squared)
+            data = solver.integrate(drift=sde.drift, diffusion=sde.diffusion, x0=x, t_span=t_span,
+                                    noise_increments=noise_increments, return_trajectory=not _final_only)
+        else:
+            raise NotImplementedError("Solver type {} is not implemented".format(type(solver).__name__))
+        if _final_only:
+            data = data.unsqueeze(0)
+        data = reshape_output(self, data, batch_size, extra, n, x_0, condition)
+        return data[-1] if _final_only else data
+
+    # ------------------------------------------------------------------ training
+    def score_matching_loss(self, x, condition=None, weighting_scheme: str = None, average: bool = True,
+                            t=None, noise=None):
+        """diffusion_model.py:1006-1041 -> score_function.py:83-251.  ``t`` / ``noise`` (superset)
+        replace the internal draws."""
+        t, x_t, alpha, beta, target = prepare_score_matching(self, self.model_type, self.diffusion_process, x,
+                                                             self.gaussian_generator, weighting_scheme, t, noise)
+        return fused_loss(self.model, t, x_t, condition, alpha, beta, target, average)
+
+    def flow_matching_loss(self, x, condition=None, average: bool = True, t=None, noise=None):
+        """diffusion_model.py:1064-1081 -> velocity_function.py:81-218."""
+        t, x_t, alpha, beta, target = prepare_flow_matching(self.model_type, self.diffusion_process, x,
+                                                            self.gaussian_generator, t, noise)
+        return fused_loss(self.model, t, x_t, condition, alpha, beta, target, average)

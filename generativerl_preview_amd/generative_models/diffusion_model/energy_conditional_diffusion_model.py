@@ -1,0 +1,79 @@
+"""EnergyConditionalDiffusionModel (QGPO), grl/generative_models/diffusion_model/
+energy_conditional_diffusion_model.py:29-1394: a diffusion model plus an energy-guidance net; guided
+sampling integrates score + guidance_scale * dE/dx, with the Q-gradient evaluated inside the same
+fused step (csrc/engine_f32.hip.inc ``k_sample_f32``)."""
+import torch
+import torch.nn as nn
+
+from ...config import as_config
+from ..diffusion_process import GuidedScore
+from ..intrinsic_model import IntrinsicModel
+from .diffusion_model import DiffusionModel
+
+
+class EnergyGuidance(nn.Module):
+    """energy_conditional_diffusion_model.py:29-92"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = as_config(config)
+        self.model = IntrinsicModel(self.config)
+
+    def forward(self, t, x, condition=None):
+        return self.model(t, x, condition)
+
+    def calculate_energy_guidance(self, t, x, condition=None, guidance_scale: float = 1.0):
+        """guidance_scale * d/dx sum E(t, x, c) (:67-92), one fused forward+input-gradient launch."""
+        m = self.model
+        if not hasattr(m, "_io_dims"):
+            m.set_io_dims(x.shape[-1], 0 if condition is None else condition.shape[-1])
+        t = t.expand(x.shape[0]) if t.dim() == 0 else t
+        return m.plan.energy_grad(m.packed(), t, x, condition, guidance_scale)
+
+
+class EnergyConditionalDiffusionModel(DiffusionModel):
+    def __init__(self, config, energy_model=None) -> None:
+        config = as_config(config)
+        super().__init__(config)
+        self.energy_model = energy_model
+        self.energy_guidance = EnergyGuidance(config.energy_guidance)
+        x_dim = config.x_size if isinstance(config.x_size, int) else int(torch.Size(config.x_size).numel())
+        bb = config.model.args.backbone.args
+        self.energy_guidance.model.set_io_dims(x_dim, bb.condition_dim if hasattr(bb, "condition_dim") else 0)
+
+    def get_type(self):
+        return "EnergyConditionalDiffusionModel"
+
+    def _function(self, guidance_scale):
+        # the reference always integrates the guided score, also for guidance_scale == 0
+        # (energy_conditional_diffusion_model.py:406-435; qgpo.py:479)
+        gs = 1.0 if guidance_scale is None else guidance_scale
+        return GuidedScore(self.model, self.model_type, self.energy_guidance.model, gs), "score_function"
+
+    def sample(self, t_span=None, batch_size=None, x_0=None, condition=None, guidance_scale: float = 1.0,
+               with_grad: bool = False, solver_config=None, **kw):
+        """:168-213"""
+        return super().sample_forward_process(t_span=t_span, batch_size=batch_size, x_0=x_0, condition=condition,
+                                              with_grad=with_grad, solver_config=solver_config, _final_only=True,
+                                              _guidance_scale=guidance_scale, **kw)
+
+    def sample_forward_process(self, t_span=None, batch_size=None, x_0=None, condition=None,
+                               guidance_scale: float = 1.0, with_grad: bool = False, solver_config=None, **kw):
+        """:257-615"""
+        return super().sample_forward_process(t_span=t_span, batch_size=batch_size, x_0=x_0, condition=condition,
+                                              with_grad=with_grad, solver_config=solver_config,
+                                              _guidance_scale=guidance_scale, **kw)
+
+    def sample_without_energy_guidance(self, t_span=None, batch_size=None, x_0=None, condition=None,
+                                       with_grad: bool = False, solver_config=None):
+        """:215-255"""
+        return self.sample(t_span=t_span, batch_size=batch_size, x_0=x_0, condition=condition, guidance_scale=0.0,
+                           with_grad=with_grad, solver_config=solver_config)
+
+    def score_function_with_energy_guidance(self, t, x, condition=None, guidance_scale: float = 1.0):
+        """:1109-1133"""
+        from ..fused import _head_to_score
+        net = self.model(t, x, condition)
+        p, q = _head_to_score(self.model_type, self.path, t)
+        return p[:, None] * net + q[:, None] * x + self.energy_guidance.calculate_energy_guidance(
+            t, x, condition, guidance_scale)

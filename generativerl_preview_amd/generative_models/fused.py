@@ -1,0 +1,104 @@
+"""Descriptors that let the solvers hand a whole integration to the fused HIP integrator.
+
+The reference builds Python closures (``DiffusionProcess.reverse_ode(...).drift``) and lets a
+third-party integrator call them once per step.  Every such closure has the form
+    drift(t, x) = a(tau) x + b(tau) net(tau, x, c) + g(tau) dE/dx(tau, x, c),   tau = T - t (or t),
+with scalar schedule coefficients, so here the closure is replaced by a ``FusedDrift`` that can
+(1) tabulate (tau, dt, a, b, g, s) for a given time grid on the host and (2) name the packed
+network(s) -- ``ODESolver`` / ``SDESolver`` pass both to ``grlhip_sample_ode`` / ``grlhip_sample_sde``.
+Coefficient formulas: grl/generative_models/diffusion_process.py:742-919 (reverse SDE / ODE) with the
+head conversions of model_functions/score_function.py:64-80 folded in for guided sampling."""
+import torch
+
+from .. import _lib as L
+
+
+def _head_to_score(model_type, path, tau):
+    """score = p * net + q * x  (ScoreFunction.forward, score_function.py:64-80)."""
+    one, zero = torch.ones_like(tau), torch.zeros_like(tau)
+    if model_type == "noise_function":
+        return -one / path.std(tau), zero
+    if model_type == "score_function":
+        return one, zero
+    if model_type == "velocity_function":
+        g2 = path.diffusion_squared(tau)
+        return -2.0 / g2, 2.0 * path.drift_coefficient(tau) / g2
+    if model_type == "data_prediction_function":
+        cov = path.covariance(tau)
+        return path.scale(tau) / cov, -one / cov
+    raise NotImplementedError("Unknown type of function {}".format(model_type))
+
+
+class FusedDrift:
+    """kind: 'reverse_ode' | 'reverse_sde' | 'icfm'."""
+
+    def __init__(self, kind, model, model_type, path=None, reverse_path=None, condition=None,
+                 guidance=None, guidance_scale=0.0, T=1.0):
+        self.kind, self.model, self.model_type = kind, model, model_type
+        self.path, self.reverse_path, self.condition = path, reverse_path, condition
+        self.guidance, self.guidance_scale, self.T = guidance, float(guidance_scale), T
+
+    # ---- per-step coefficients at solver times t (1-D fp32 CPU tensor) -> tau, a, b, g, s
+    def coefficients(self, t):
+        t = t.detach().to("cpu", torch.float32)
+        zero = torch.zeros_like(t)
+        if self.kind == "icfm":
+            # drift = model(t, x, c), conditional_flow_model/independent_conditional_flow_model.py:285-288
+            return t, zero, torch.ones_like(t), zero, zero
+        tau = torch.tensor(self.T, dtype=torch.float32) - t
+        p, mt = self.path, self.model_type
+        f, g2 = p.drift_coefficient(tau), p.diffusion_squared(tau)
+        if self.kind == "reverse_sde":
+            rp = self.reverse_path
+            gr2, s = rp.diffusion_squared(tau), rp.diffusion(tau)
+        else:
+            gr2, s = None, zero
+        if self.guidance is not None:
+            # the guided score is integrated as a 'score_function' closure
+            # (energy_conditional_diffusion_model.py:406-435,472-508): coefficient of the score ...
+            cs = 0.5 * g2 if gr2 is None else 0.5 * (g2 + gr2)
+            hp, hq = _head_to_score(mt, p, tau)
+            return tau, -f + cs * hq, cs * hp, cs * self.guidance_scale, s
+        if self.kind == "reverse_ode":  # diffusion_process.py:853-919
+            if mt == "score_function":
+                return tau, -f, 0.5 * g2, zero, s
+            if mt == "noise_function":
+                return tau, -f, -0.5 * g2 / p.std(tau), zero, s
+            if mt == "velocity_function":
+                return tau, zero, -torch.ones_like(t), zero, s
+            if mt == "data_prediction_function":
+                D = 0.5 * g2 / p.covariance(tau)
+                return tau, -(f + D), p.scale(tau) * D, zero, s
+        else:  # diffusion_process.py:742-851
+            if mt == "score_function":
+                return tau, -f, 0.5 * (g2 + gr2), zero, s
+            if mt == "noise_function":
+                return tau, -f, -0.5 * (g2 + gr2) / p.std(tau), zero, s
+            if mt == "velocity_function":
+                r = gr2 / (g2 + 1e-8)
+                return tau, r * f, -(1.0 + r), zero, s
+            if mt == "data_prediction_function":
+                D = 0.5 * (g2 + gr2) / p.covariance(tau)
+                return tau, -(f + D), p.scale(tau) * D, zero, s
+        raise NotImplementedError("Unknown type of function {}".format(mt))
+
+    def table(self, t_steps, dts, emit, lerp):
+        tau, a, b, g, s = self.coefficients(t_steps)
+        tab = torch.stack([tau, dts.to(torch.float32), a, b, g, s, emit.to(torch.float32), lerp.to(torch.float32)], 1)
+        assert tab.shape[1] == L.COEF_STRIDE
+        return tab.contiguous()
+
+    # ---- launch
+    def integrate(self, x0, table, increments=None, trajectory_slots=0, dtype=None):
+        m = self.model
+        dtype = m.compute_dtype if dtype is None else dtype
+        g_plan = g_packed = None
+        if self.guidance is not None:
+            g_plan, g_packed = self.guidance.plan, self.guidance.packed(L.F32 if dtype == L.F32 else dtype)
+        return m.plan.sample(m.packed(dtype), x0, self.condition, table, dW=increments, guidance=g_plan,
+                             guidance_packed=g_packed, trajectory_slots=trajectory_slots, dtype=dtype)
+
+    # a FusedDrift is also callable like the reference closure (one fused launch of a single step
+    # evaluation is not provided; the solvers never call it)
+    def __call__(self, t, x):
+        raise NotImplementedError("FusedDrift is consumed whole by ODESolver/SDESolver.integrate")

@@ -1,0 +1,86 @@
+"""IntrinsicModel (grl/generative_models/intrinsic_model.py:12-75): t_encoder -> backbone(t, x[, c]),
+built from config through the encoder / module registries.
+
+The parameters live in ordinary ``nn.Parameter``s under the reference's names
+(``model.t_encoder.W``, ``model.backbone.sort_t.0.weight`` ...).  ``forward`` evaluates the whole
+network in the HIP library (``grlhip_net_forward``); the packed weight image is derived from the
+parameters and refreshed whenever a parameter's version counter changes."""
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from ..config import as_config
+from ..engine import NetPlan
+from ..neural_network import ConcatenateMLP, TemporalSpatialResidualNet, get_module
+from ..neural_network.encoders import GaussianFourierProjectionTimeEncoder, get_encoder
+
+
+class IntrinsicModel(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        config = as_config(config)
+        self.config = config
+        assert hasattr(config, "backbone"), "backbone must be specified in config"
+        self.model = nn.ModuleDict()
+        for enc in ("t_encoder", "x_encoder", "condition_encoder"):
+            if hasattr(config, enc):
+                self.model[enc] = get_encoder(config[enc].type)(**config[enc].args)
+            else:
+                self.model[enc] = nn.Identity()
+        self.model["backbone"] = get_module(config.backbone.type)(**config.backbone.args)
+        self.compute_dtype = L.F32
+        self._plan = None
+        self._packed = {}
+
+    # ------------------------------------------------------------------ HIP plumbing
+    @property
+    def plan(self) -> NetPlan:
+        if self._plan is None:
+            te, bb = self.model["t_encoder"], self.model["backbone"]
+            if not isinstance(te, GaussianFourierProjectionTimeEncoder) or \
+                    not isinstance(self.model["x_encoder"], nn.Identity) or \
+                    not isinstance(self.model["condition_encoder"], nn.Identity):
+                raise NotImplementedError("the fused kernels need a GaussianFourierProjectionTimeEncoder t_encoder "
+                                          "and identity x/condition encoders")
+            if isinstance(bb, TemporalSpatialResidualNet):
+                d = bb.hip_desc()
+                assert d["t_dim"] == te.embed_dim, "backbone t_dim must equal the t_encoder embed_dim"
+                self._plan = NetPlan(L.NET_RESNET, d["x_dim"], d["out_dim"], d["cond_dim"], d["t_dim"],
+                                     d["cond_hidden"], d["t_cond_hidden"], d["hidden"])
+            elif isinstance(bb, ConcatenateMLP):
+                d = bb.hip_desc()
+                # input is cat[t_emb, x, c]; x/c split is fixed at first use (set_io_dims)
+                if not hasattr(self, "_io_dims"):
+                    raise RuntimeError("ConcatenateMLP IntrinsicModel: call set_io_dims(x_dim, cond_dim) first")
+                x_dim, c_dim = self._io_dims
+                assert d["in_dim"] == te.embed_dim + x_dim + c_dim, "ConcatenateMLP input width mismatch"
+                self._plan = NetPlan(L.NET_CONCAT_MLP, x_dim, d["out_dim"], c_dim, te.embed_dim, 0, 0, d["hidden"])
+            else:
+                raise NotImplementedError("no fused kernel for backbone %s" % type(bb).__name__)
+        return self._plan
+
+    def set_io_dims(self, x_dim, cond_dim):
+        self._io_dims = (int(x_dim), int(cond_dim or 0))
+
+    def _named(self):
+        sd = {k: v for k, v in self.model.named_parameters()}
+        return {name: sd[name] for name, _ in self.plan.params}
+
+    def packed(self, dtype=None):
+        dtype = self.compute_dtype if dtype is None else dtype
+        named = self._named()
+        key = tuple((p.data_ptr(), p._version) for p in named.values())
+        hit = self._packed.get(dtype)
+        if hit is None or hit[0] != key:
+            hit = (key, self.plan.pack(named, dtype))
+            self._packed[dtype] = hit
+        return hit[1]
+
+    # ------------------------------------------------------------------ reference API
+    def forward(self, t, x, condition=None):
+        """intrinsic_model.py:54-75.  Not differentiable: training goes through the fused
+        ``*_loss`` entry points."""
+        if isinstance(self.model["backbone"], ConcatenateMLP) and not hasattr(self, "_io_dims"):
+            self.set_io_dims(x.shape[-1], 0 if condition is None else condition.shape[-1])
+        t = t.expand(x.shape[0]) if t.dim() == 0 else t
+        return self.plan.forward(self.packed(L.F32), t, x, condition, L.F32)

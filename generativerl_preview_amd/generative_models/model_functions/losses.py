@@ -1,0 +1,165 @@
+"""The training losses of the hot path, reduced to ONE fused forward+backward kernel call.
+
+Every variant of ScoreFunction.score_matching_loss (grl/generative_models/model_functions/
+score_function.py:192-251), VelocityFunction.flow_matching_loss (velocity_function.py:131-214) and
+flow_matching_loss_icfm (:289-296) is
+    pred = alpha(t) * net(t, x_t, c) + beta(t) * x_t ;   loss_row = sum_d 0.5 * (pred - target)^2
+The ``prepare_*`` functions draw t / noise in the reference's order (t first, then the noise),
+build x_t, alpha, beta and target with a handful of elementwise device ops, and ``fused_loss`` runs
+the network forward+backward in the HIP library (``grlhip_loss_fwd_bwd``), exposing the result to
+autograd so ``loss.backward()`` fills ``.grad`` of the ordinary parameters."""
+import ctypes
+
+import torch
+
+from ... import _lib as L
+from ...engine import _f32c, _ptr, _stream
+from ...numerical_methods.monte_carlo import MonteCarloSampler
+
+
+def _bc(v, x):
+    return v[(...,) + (None,) * (x.dim() - v.dim())].expand(x.shape) if x.dim() > v.dim() else v
+
+
+def _draw_t(fn_owner, process, batch_size, device, weighting_scheme):
+    if weighting_scheme is None or weighting_scheme == "maximum_likelihood":
+        if not hasattr(fn_owner, "monte_carlo_sampler"):  # score_function.py:129-143
+            fn_owner.monte_carlo_sampler = MonteCarloSampler(
+                unnormalized_pdf=lambda t: process.path.diffusion_squared(t) / (process.path.covariance(t) + 1e-6),
+                x_min=0.0, x_max=process.t_max, device=device)
+        return fn_owner.monte_carlo_sampler.sample(batch_size).to(device=device)
+    if weighting_scheme == "vanilla":
+        eps = 1e-5
+        return torch.rand(batch_size, device=device) * (process.t_max - eps) + eps
+    raise NotImplementedError("Unknown weighting scheme {}".format(weighting_scheme))
+
+
+def prepare_score_matching(owner, model_type, process, x, gaussian_generator, weighting_scheme, t=None, noise=None):
+    B, dev = x.shape[0], x.device
+    if t is None:
+        t = _draw_t(owner, process, B, dev, weighting_scheme)
+    if noise is None:
+        noise = torch.randn_like(x) if gaussian_generator is None else gaussian_generator(B)
+    p = process.path
+    std, scale = p.std(t), p.scale(t)
+    x_t = _bc(scale, x) * x + _bc(std, x) * noise
+    one, zero = torch.ones_like(t), torch.zeros_like(t)
+    if model_type == "noise_function":
+        alpha, beta = one, zero
+    elif model_type == "score_function":
+        alpha, beta = std, zero
+    elif model_type == "velocity_function":
+        k = 2.0 * std / p.diffusion_squared(t)
+        alpha, beta = k, -p.drift_coefficient(t) * k
+    elif model_type == "data_prediction_function":
+        alpha, beta = -scale / std, one / std
+    else:
+        raise NotImplementedError("Unknown type of score function {}".format(model_type))
+    return t, x_t, alpha, beta, noise
+
+
+def prepare_flow_matching(model_type, process, x, gaussian_generator, t=None, noise=None):
+    B, dev = x.shape[0], x.device
+    eps = 1e-5
+    if t is None:
+        t = torch.rand(B, device=dev) * (process.t_max - eps) + eps
+    if noise is None:
+        noise = torch.randn_like(x) if gaussian_generator is None else gaussian_generator(B)
+    p = process.path
+    std, scale = p.std(t), p.scale(t)
+    x_t = _bc(scale, x) * x + _bc(std, x) * noise
+    f, g2 = p.drift_coefficient(t), p.diffusion_squared(t)
+    one, zero = torch.ones_like(t), torch.zeros_like(t)
+    if model_type == "noise_function":
+        alpha, beta = 0.5 * g2 / std, f
+    elif model_type == "score_function":
+        alpha, beta = -0.5 * g2, f
+    elif model_type == "velocity_function":
+        alpha, beta = one, zero
+    elif model_type == "data_prediction_function":
+        D = 0.5 * g2 / p.covariance(t)
+        alpha, beta = -D * scale, f + D
+    else:
+        raise NotImplementedError("Unknown type of velocity function {}".format(model_type))
+    target = process.velocity(t, x, noise=noise)
+    return t, x_t, alpha, beta, target
+
+
+def prepare_icfm(process, x0, x1, t=None, noise=None):
+    """flow_matching_loss_icfm (velocity_function.py:289-296) + StochasticProcess.direct_sample
+    (stochastic_process.py:108-129): t = rand(B) * t_max, x_t = x0 (1-t) + x1 t + sigma * randn."""
+    B, dev = x0.shape[0], x0.device
+    if t is None:
+        t = torch.rand(B, device=dev) * process.t_max
+    if noise is None:
+        noise = torch.randn_like(x0)
+    x_t = process.mean(t, x0, x1) + process.std(t, x0, x1) * noise
+    return t, x_t, torch.ones_like(t), torch.zeros_like(t), process.velocity(t, x0, x1)
+
+
+class _FusedLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, t, x_t, cond, alpha, beta, target, average, *params):
+        plan = model.plan
+        B = x_t.shape[0]
+        dev = x_t.device
+        lib = L.lib()
+        loss_rows = torch.empty(B, dtype=torch.float32, device=dev)
+        n_grad = lib.grlhip_grad_numel(plan.handle)
+        need_grad = any(p.requires_grad for p in params)
+        flat = torch.zeros(n_grad, dtype=torch.float32, device=dev) if (need_grad and average) else None
+        roww = torch.full((B,), 1.0 / B, dtype=torch.float32, device=dev) if flat is not None else None
+        _launch(model, t, x_t, cond, alpha, beta, target, roww, loss_rows, flat)
+        ctx.model, ctx.average, ctx.flat = model, average, flat
+        ctx.n_params = len(params)
+        if not average:
+            ctx.save_for_backward(t, x_t, cond if cond is not None else torch.empty(0, device=dev), alpha, beta, target)
+            ctx.has_cond = cond is not None
+            return loss_rows
+        return loss_rows.mean()
+
+    @staticmethod
+    def backward(ctx, gout):
+        model = ctx.model
+        plan = model.plan
+        if ctx.average:
+            flat = ctx.flat * gout
+        else:
+            t, x_t, cond, alpha, beta, target = ctx.saved_tensors
+            flat = torch.zeros(L.lib().grlhip_grad_numel(plan.handle), dtype=torch.float32, device=x_t.device)
+            scratch = torch.empty(x_t.shape[0], dtype=torch.float32, device=x_t.device)
+            _launch(model, t, x_t, cond if ctx.has_cond else None, alpha, beta, target,
+                    gout.contiguous().float(), scratch, flat)
+        grads = []
+        named = model._named()
+        names = [n for n, _ in plan.params]
+        for i, (name, shape) in enumerate(plan.params):
+            p = named[name]
+            if p.requires_grad:
+                off = L.lib().grlhip_grad_offset(plan.handle, i)
+                grads.append(flat[off:off + p.numel()].view(p.shape))
+            else:
+                grads.append(None)
+        assert len(names) == ctx.n_params
+        return (None, None, None, None, None, None, None, None, *grads)
+
+
+def _launch(model, t, x_t, cond, alpha, beta, target, roww, loss_rows, flat):
+    plan = model.plan
+    B, dev = x_t.shape[0], x_t.device
+    lib = L.lib()
+    t, x_t, cond = _f32c(t, "t", (B,)), _f32c(x_t, "x_t", (B, plan.x_dim)), _f32c(cond, "condition")
+    alpha, beta, target = _f32c(alpha, "alpha", (B,)), _f32c(beta, "beta", (B,)), _f32c(target, "target", x_t.shape)
+    need = lib.grlhip_loss_workspace_bytes(plan.handle, B, L.F32)
+    ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        L.check(lib.grlhip_loss_fwd_bwd(plan.handle, _ptr(model.packed(L.F32)), L.F32, _ptr(t), _ptr(x_t), _ptr(cond),
+                                        _ptr(alpha), _ptr(beta), _ptr(target), _ptr(roww), _ptr(loss_rows),
+                                        _ptr(flat), B, _ptr(ws), ws.numel(), _stream(dev)))
+
+
+def fused_loss(model, t, x_t, cond, alpha, beta, target, average=True):
+    """model: IntrinsicModel.  Returns the scalar mean loss (average=True) or the per-row losses."""
+    named = model._named()
+    params = [named[n] for n, _ in model.plan.params]
+    return _FusedLoss.apply(model, t, x_t, cond, alpha, beta, target, average, *params)

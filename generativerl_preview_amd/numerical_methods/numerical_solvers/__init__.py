@@ -1,0 +1,15 @@
+"""Solver registry (grl/numerical_methods/numerical_solvers/__init__.py:6-18)."""
+from .ode_solver import ODESolver
+from .sde_solver import SDESolver
+
+
+def get_solver(solver_type):
+    if solver_type.lower() in SOLVERS:
+        return SOLVERS[solver_type.lower()]
+    raise ValueError(f"Solver type {solver_type} not recognized")
+
+
+SOLVERS = {
+    "ODESolver".lower(): ODESolver,
+    "SDESolver".lower(): SDESolver,
+}

@@ -1,0 +1,164 @@
+/* grlhip -- C ABI of the MI355X-native generative-policy hot path.
+ *
+ * The reference (zjowowen/GenerativeRL_Preview) is pure Python and has no FFI; this ABI is what
+ * the Python classes that mirror its API (generativerl_preview_amd/) bind through ctypes, one
+ * entry point per reference code path (cited per function, paths relative to the reference root).
+ *
+ * Conventions: every function returns 0 on success or a negative grlhip_status; the text of the
+ * last failure on the calling thread is available from grlhip_last_error().  Nothing throws.
+ * All data pointers are DEVICE pointers (fp32, row-major, contiguous) unless a comment says
+ * "host"; the library never allocates or frees caller memory: scratch space is a caller-owned
+ * workspace whose size comes from grlhip_workspace_bytes().  Every launch goes to the explicit
+ * `stream` argument (a hipStream_t passed as void*; NULL = the null stream).  Calls on distinct
+ * plans/workspaces may run concurrently; a workspace must not be shared by overlapping calls.
+ */
+#ifndef GRLHIP_H
+#define GRLHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRLHIP_MAX_HIDDEN 8
+
+typedef enum {
+  GRLHIP_OK = 0,
+  GRLHIP_ERR_INVALID = -1,     /* bad argument / inconsistent sizes */
+  GRLHIP_ERR_UNSUPPORTED = -2, /* shape or mode this build has no kernel for */
+  GRLHIP_ERR_HIP = -3,         /* a HIP runtime call failed */
+  GRLHIP_ERR_WORKSPACE = -4    /* workspace missing or too small */
+} grlhip_status;
+
+typedef enum {
+  GRLHIP_NET_RESNET = 0,    /* TemporalSpatialResidualNet, grl/neural_network/__init__.py:237-342 */
+  GRLHIP_NET_CONCAT_MLP = 1 /* ConcatenateMLP(SiLU) -> 1 output, grl/neural_network/__init__.py:558-583 */
+} grlhip_net_kind;
+
+typedef enum {
+  GRLHIP_F32 = 0, /* fp32 storage, fp32-input MFMA (exact fp32 fma chains) */
+  GRLHIP_BF16 = 1 /* bf16 weights/activations, fp32 accumulate, fp32 state and schedule math */
+} grlhip_dtype;
+
+/* Network description = the constructor arguments of the reference module.
+ * RESNET:     x_dim -> hidden[0..n_hidden) U-Net of TemporalSpatialResBlocks -> out_dim; t_dim is the
+ *             width of the GaussianFourierProjectionTimeEncoder output (encoders.py:36-86);
+ *             cond_dim == 0 means unconditional (then cond_hidden is ignored, t_cond_hidden = t_dim).
+ * CONCAT_MLP: input cat[t_emb(t_dim), x(x_dim), c(cond_dim)] -> hidden[0..n_hidden) with SiLU -> out_dim (1). */
+typedef struct {
+  int32_t kind;
+  int32_t x_dim;
+  int32_t out_dim;
+  int32_t cond_dim;
+  int32_t t_dim;
+  int32_t cond_hidden;
+  int32_t t_cond_hidden;
+  int32_t n_hidden;
+  int32_t hidden[GRLHIP_MAX_HIDDEN];
+} grlhip_net_desc;
+
+typedef struct grlhip_plan grlhip_plan; /* opaque; immutable after creation */
+
+const char* grlhip_last_error(void);
+/* 1 when a HIP device is usable by this process, else 0 (never fails). */
+int grlhip_device_available(void);
+
+/* Replaces: module construction through get_module()/get_encoder(),
+ * grl/generative_models/intrinsic_model.py:19-52.  Builds the op program, the activation-slab
+ * layout and the packed-weight layout for `net`; uploads the (tiny) program to the current device. */
+int grlhip_plan_create(const grlhip_net_desc* net, grlhip_plan** out_plan);
+void grlhip_plan_destroy(grlhip_plan* plan);
+
+/* The parameters the plan consumes, in packing order, named as in the reference state_dict
+ * relative to the IntrinsicModel's ModuleDict ("t_encoder.W", "backbone.sort_t.0.weight", ...;
+ * SURVEY.md section 5 "Checkpoint").  rows/cols: cols == 0 for vectors. */
+int grlhip_plan_num_params(const grlhip_plan* plan);
+int grlhip_plan_param_info(const grlhip_plan* plan, int index, char* name_buf, size_t name_buf_len,
+                           int32_t* rows, int32_t* cols);
+
+/* Bytes of the packed weight image for `dtype`. */
+size_t grlhip_packed_bytes(const grlhip_plan* plan, int dtype);
+/* Derive the packed (padded / transposed / fragment-ordered) weight image from the reference-layout
+ * parameters.  `params` is a HOST array of n DEVICE pointers (fp32), in grlhip_plan_param_info order. */
+int grlhip_pack_weights(const grlhip_plan* plan, const void* const* params, int n, int dtype,
+                        void* packed, void* stream);
+
+/* Workspace bytes for a call over `rows` rows (sampling / forward); `guidance` may be NULL. */
+size_t grlhip_workspace_bytes(const grlhip_plan* plan, const grlhip_plan* guidance, int64_t rows, int dtype);
+
+/* Replaces: IntrinsicModel.forward, grl/generative_models/intrinsic_model.py:54-75 --
+ * out[R,out_dim] = backbone(fourier(t[R]), x[R,x_dim], cond[R,cond_dim] | NULL). */
+int grlhip_net_forward(const grlhip_plan* plan, const void* packed, int dtype, const float* t,
+                       const float* x, const float* cond, float* out, int64_t rows,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* Replaces: EnergyGuidance.calculate_energy_guidance,
+ * grl/generative_models/diffusion_model/energy_conditional_diffusion_model.py:67-92 --
+ * grad[R,x_dim] = scale * d/dx sum_rows E(t, x, cond) for a CONCAT_MLP plan. */
+int grlhip_energy_grad(const grlhip_plan* plan, const void* packed, int dtype, const float* t,
+                       const float* x, const float* cond, float scale, float* grad, int64_t rows,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* Per-step coefficients of the fused integrator, a HOST-computed DEVICE table coef[n_steps][8]:
+ *   [0] tau    time fed to the network at this step
+ *   [1] dt     step length
+ *   [2] a      x_{k+1} = x_k + dt * (a*x_k + b*net(tau,x_k,c) + g*dE/dx(tau,x_k,c)) + s*dW_k
+ *   [3] b
+ *   [4] g      guidance coefficient (0.5*g^2(tau)*guidance_scale for the reverse ODE)
+ *   [5] s      diffusion coefficient multiplying the caller's Brownian increment (0 for ODEs)
+ *   [6] emit   >= 0: after this step copy the state to out_traj[emit] (only if out_traj != NULL);
+ *              stored as float
+ *   [7] lerp   weight w for the emitted state: out = x_prev + w*(x_new - x_prev) (1 = x_new),
+ *              reproducing torchsde's interpolation to requested output times.
+ * This covers every (model head x path x solver) closure of DiffusionProcess.reverse_ode / reverse_sde
+ * (grl/generative_models/diffusion_process.py:742-919) and the ICFM drift
+ * (conditional_flow_model/independent_conditional_flow_model.py:285-288). */
+#define GRLHIP_COEF_STRIDE 8
+
+/* Replaces: ODESolver.integrate with Euler on the caller's grid
+ * (grl/numerical_methods/numerical_solvers/ode_solver.py:51-79,168-185) driven from
+ * DiffusionModel.sample_forward_process (diffusion_model/diffusion_model.py:282-304) /
+ * EnergyConditionalDiffusionModel (:406-435) / IndependentConditionalFlowModel (:285-319):
+ * all n_steps Euler steps of all rows in ONE launch.  guidance/guidance_packed may be NULL.
+ * out_final[R,D] always written; out_traj[n_emit+1, R, D] optional (slot 0 = x0). */
+int grlhip_sample_ode(const grlhip_plan* plan, const void* packed, int dtype,
+                      const grlhip_plan* guidance, const void* guidance_packed,
+                      const float* x0, const float* cond, const float* coef, int32_t n_steps,
+                      int64_t rows, float* out_final, float* out_traj,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* Replaces: SDESolver.integrate -> torchsde.sdeint(method="euler")
+ * (grl/numerical_methods/numerical_solvers/sde_solver.py:92-144) for the reverse SDE closures
+ * (diffusion_process.py:742-851): Euler-Maruyama y += f*dt + g*dW with the Brownian increments read
+ * from the caller's buffer dW[n_steps, R, D] (already scaled by sqrt(dt)), so runs are reproducible. */
+int grlhip_sample_sde(const grlhip_plan* plan, const void* packed, int dtype,
+                      const grlhip_plan* guidance, const void* guidance_packed,
+                      const float* x0, const float* cond, const float* coef, const float* dW,
+                      int32_t n_steps, int64_t rows, float* out_final, float* out_traj,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* Workspace bytes for grlhip_loss_fwd_bwd over `rows` rows. */
+size_t grlhip_loss_workspace_bytes(const grlhip_plan* plan, int64_t rows, int dtype);
+/* Number of fp32 elements of the flat gradient buffer (all parameters in param_info order). */
+int64_t grlhip_grad_numel(const grlhip_plan* plan);
+/* Offset (in elements) of parameter `index` inside the flat gradient buffer. */
+int64_t grlhip_grad_offset(const grlhip_plan* plan, int index);
+
+/* Replaces: the forward + autograd backward of ScoreFunction.score_matching_loss
+ * (grl/generative_models/model_functions/score_function.py:83-251), VelocityFunction.flow_matching_loss
+ * (velocity_function.py:81-218) and flow_matching_loss_icfm (:220-302).  Every variant is
+ *   pred = alpha[r]*net(t[r], x_t[r], c[r]) + beta[r]*x_t[r];  loss_r = sum_d 0.5*(pred - target)^2
+ * loss_rows[R] receives loss_r; grad_flat (+=) receives sum_r row_weight[r] * d loss_r / d theta
+ * (row_weight NULL = 1).  grad_flat is NOT zeroed by the call. */
+int grlhip_loss_fwd_bwd(const grlhip_plan* plan, const void* packed, int dtype, const float* t,
+                        const float* x_t, const float* cond, const float* alpha, const float* beta,
+                        const float* target, const float* row_weight, float* loss_rows,
+                        float* grad_flat, int64_t rows, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRLHIP_H */

@@ -1,0 +1,150 @@
+"""GPU parity: the HIP path (through the C ABI) against the committed goldens and against the CPU
+oracle on larger seeded inputs.  fp32 engine tolerance: max-abs 1e-4 on O(1) states (north_star)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_lib as gl
+import golden_util as gu
+import util_models as um
+from generativerl_preview_amd import _lib as L
+from oracle import grl_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ALL = gu.CANON + gu.SMALL
+TOL = 1e-4  # north_star: fp32 final actions within max-abs 1e-4
+
+
+def close(a, b, tol=TOL, what=""):
+    a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().double().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(1.0, float(np.max(np.abs(b))))
+    err = float(np.max(np.abs(a - b)))
+    assert err <= tol * scale, "%s: max-abs err %.3e (scale %.2e, tol %.1e)" % (what, err, scale, tol)
+
+
+def cu(a):
+    return None if a is None else torch.as_tensor(np.asarray(a)).to(DEV)
+
+
+def test_library_loaded_and_device_visible():
+    assert L.device_available()
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_net_forward_vs_golden(name):
+    kind, cfg, m = um.build(name, DEV)
+    g = gu.load("model_%s.npz" % name)
+    out = m.model(cu(g["t"]), cu(g["x"]), cu(g.get("cond")))
+    close(out, g["net"], what="net")
+
+
+@pytest.mark.parametrize("name", ["qgpo_noise", "small_energy"])
+def test_energy_guidance_vs_golden(name):
+    kind, cfg, m = um.build(name, DEV)
+    g = gu.load("model_%s.npz" % name)
+    t, x, c = cu(g["t"]), cu(g["x"]), cu(g["cond"])
+    close(m.energy_guidance(t, x, c), g["energy"], what="energy")
+    for s in (0.0, 1.0, 5.0):
+        close(m.energy_guidance.calculate_energy_guidance(t, x, c, s), g["guidance_%g" % s], what="guidance")
+        close(m.score_function_with_energy_guidance(t, x, c, s), g["guided_score_%g" % s], what="guided score")
+
+
+def _cases(s):
+    for key in sorted(s):
+        if key.startswith("traj_"):
+            parts = key.split("_")
+            yield (key, int(parts[1][1:]), None if parts[2] == "bNone" else int(parts[2][1:]), parts[3] == "x1",
+                   float(parts[4][1:]) if len(parts) > 4 else None)
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_ode_trajectories_vs_golden(name):
+    """All four (batch_size, x_0) combinations, T in {5, 32, 101}: shapes, layout quirk and values."""
+    kind, cfg, m = um.build(name, DEV)
+    s = gu.load("sample_%s.npz" % name)
+    S = gu.cond_dim(cfg)
+    n = 0
+    for key, Tn, bs, use_x0, gs in _cases(s):
+        kw = dict(t_span=torch.linspace(0.0, 1.0, Tn), batch_size=bs, x_0=cu(s["x0"]) if use_x0 else None)
+        if S:
+            kw["condition"] = cu(s["cond"])
+        if gs is not None:
+            kw["guidance_scale"] = gs
+        if not use_x0:
+            um.fix_noise(m, cu(s["xT_T%d_b%s_x0" % (Tn, bs)]))
+        traj = m.sample_forward_process(**kw)
+        close(traj, s[key], what=key)
+        final = m.sample(**kw)
+        close(final, s[key][-1], what=key + " final")
+        n += 1
+    assert n >= 4
+
+
+@pytest.mark.parametrize("name", ["small_energy", "small_uncond_noise", "swiss_noise", "qgpo_noise"])
+def test_sde_trajectories_vs_golden(name):
+    kind, cfg, m = um.build(name, DEV)
+    s = gu.load("sample_%s.npz" % name)
+    S = gu.cond_dim(cfg)
+    n = 0
+    for Tn, dt in ((11, 0.1), (21, 0.05)):
+        for key in [k for k in s if k.startswith("sde_T%d" % Tn) and not k.endswith(("dW", "xT"))]:
+            kw = dict(t_span=torch.linspace(0.0, 1.0, Tn), batch_size=2,
+                      solver_config=dict(type="SDESolver", args=dict(library="torchsde", dt=dt)),
+                      noise_increments=cu(s["sde_T%d_dW" % Tn]))
+            if S:
+                kw["condition"] = cu(s["cond"])
+            if "_g" in key:
+                kw["guidance_scale"] = float(key.split("_g")[1])
+            um.fix_noise(m, cu(s["sde_T%d_xT" % Tn]))
+            close(m.sample_forward_process(**kw), s[key], what=key, tol=2e-4)
+            n += 1
+    assert n >= 2
+
+
+@pytest.mark.parametrize("name,rows", [("qgpo_noise", 1000), ("icfm_cond", 777), ("gvp_wide", 300),
+                                       ("swiss_noise", 500), ("small_vp_data", 97), ("small_gvp_score", 65)])
+def test_ode_sampling_vs_oracle_ragged_rows(name, rows):
+    """Row counts that are not multiples of the 32-row tile; 20 Euler steps; final actions."""
+    kind, cfg, m = um.build(name, DEV)
+    sd = gu.weights(name)
+    S = gu.cond_dim(cfg)
+    D = cfg["x_size"]
+    gen = torch.Generator().manual_seed(5)
+    x0 = torch.randn(rows, D, generator=gen)
+    cond = torch.randn(rows, S, generator=gen) if S else None
+    lo, hi = (1e-3, 1.0 - 1e-3) if name == "small_gvp_score" else (0.0, 1.0)
+    t_span = torch.linspace(lo, hi, 21)
+    kw = dict(t_span=t_span, x_0=x0.to(DEV))
+    if S:
+        kw["condition"] = cond.to(DEV)
+    if kind == "energy":
+        kw["guidance_scale"] = 1.5
+    got = m.sample(**kw)
+    want = O.sample_forward_process(sd, cfg, kind, t_span, x_0=x0, condition=cond, guidance_scale=1.5)[-1]
+    assert got.shape == want.shape
+    close(got, want, what=name)
+
+
+def test_empty_batch_and_errors():
+    kind, cfg, m = um.build("small_vp_noise", DEV)
+    out = m.sample(t_span=torch.linspace(0, 1, 5), x_0=torch.zeros(0, 6, device=DEV),
+                   condition=torch.zeros(0, 17, device=DEV))
+    assert out.shape == (0, 6)
+    with pytest.raises(AssertionError):
+        m.sample(t_span=torch.linspace(0, 1, 5), x_0=torch.zeros(3, 5, device=DEV), condition=torch.zeros(3, 17, device=DEV))
+    with pytest.raises(L.GrlHipError):  # conditional net without a condition
+        m.sample(t_span=torch.linspace(0, 1, 5), x_0=torch.zeros(3, 6, device=DEV))
+
+
+def test_weights_are_repacked_after_an_update():
+    kind, cfg, m = um.build("small_uncond_noise", DEV)
+    g = gu.load("model_small_uncond_noise.npz")
+    t, x = cu(g["t"]), cu(g["x"])
+    a = m.model(t, x)
+    with torch.no_grad():
+        m.model.model["backbone"].last_block.bias.add_(1.0)
+    b = m.model(t, x)
+    close(b - a, torch.ones_like(a), what="bias shift")
