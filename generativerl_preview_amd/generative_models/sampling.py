@@ -34,10 +34,10 @@ def expand_inputs(model, batch_size, x_0, condition):
         x = model.gaussian_generator(batch_size=rep * n)
     else:
         if isinstance(model.x_size, int):
-            assert torch.Size([model.x_size]) == x_0[0].shape, \
+            assert torch.Size([model.x_size]) == x_0.shape[1:], \
                 "The shape of x_0 must be the same as the x_size that is specified in the config"
         elif isinstance(model.x_size, (Tuple, List, torch.Size)):
-            assert torch.Size(model.x_size) == x_0[0].shape, \
+            assert torch.Size(model.x_size) == x_0.shape[1:], \
                 "The shape of x_0 must be the same as the x_size that is specified in the config"
         else:
             assert False, "Invalid x_size"
