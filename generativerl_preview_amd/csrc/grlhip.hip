@@ -9,8 +9,23 @@
 #include "plan.hpp"
 using namespace grlhip;
 
+namespace grlhip {
+int device_cus() {
+  static int cus = -1;
+  if (cus < 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      cus = v;
+    else
+      cus = 256;
+  }
+  return cus;
+}
+}  // namespace grlhip
+
 #include "engine_f32.hip.inc"
-#include "engine_bf16.hip.inc"
+#include "engine_bf16_host.hip.inc"
 
 struct grlhip_plan {
   Plan* p;
@@ -29,19 +44,6 @@ int fail(int code, const std::string& msg) {
     hipError_t e_ = (expr);                                                                    \
     if (e_ != hipSuccess) return fail(GRLHIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
-
-int device_cus() {
-  static int cus = -1;
-  if (cus < 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-      cus = v;
-    else
-      cus = 256;
-  }
-  return cus;
-}
 
 // fp32 engine launch geometry: 4 waves (=4 row tiles in flight) per block, <= 4 blocks per CU
 int f32_blocks(int64_t rows) {
@@ -101,6 +103,7 @@ int grlhip_plan_create(const grlhip_net_desc* net, grlhip_plan** out_plan) {
     if (rc == 0) rc = upload(p->grad, &p->d_grad);
     if (rc != 0) { delete p; return rc; }
   }
+  bf16_plan_init(p, p->d_fwd != nullptr);
   *out_plan = new grlhip_plan{p};
   return 0;
 }
@@ -110,6 +113,7 @@ void grlhip_plan_destroy(grlhip_plan* plan) {
   if (plan->p) {
     if (plan->p->d_fwd) (void)hipFree(plan->p->d_fwd);
     if (plan->p->d_grad) (void)hipFree(plan->p->d_grad);
+    bf16_plan_free(plan->p);
     delete plan->p;
   }
   delete plan;

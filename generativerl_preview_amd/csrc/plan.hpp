@@ -13,6 +13,9 @@
 
 namespace grlhip {
 
+constexpr int GRLHIP_BF16_MAX_STEPS = 4096;  // rows of the per-step Fourier table in the bf16 workspace
+int device_cus();                            // CU count of the current device (256 when none is visible)
+
 enum OpType : int32_t {
   OP_LINEAR = 0,         // out[n] = act(sum_k W[n][k] in[k] + b[n]) (+ slab[add + n])
   OP_SILU = 1,           // out[n] = silu(in[n])
@@ -58,6 +61,7 @@ struct Plan {
   // device copies of the programs (uploaded at creation)
   void* d_fwd = nullptr;
   void* d_grad = nullptr;
+  void* bf16 = nullptr;      // Bf16Layout* (engine_bf16.hip.inc), null when the shape has no bf16 kernel
   std::string error;
 };
 

@@ -148,3 +148,65 @@ def test_weights_are_repacked_after_an_update():
         m.model.model["backbone"].last_block.bias.add_(1.0)
     b = m.model(t, x)
     close(b - a, torch.ones_like(a), what="bias shift")
+
+
+# ----------------------------------------------------------------------------- bf16 MFMA engine
+BF16_TOL = 2e-2  # north_star: bf16 final actions within max-abs 2e-2
+
+
+def _bf16_model(name):
+    import generativerl_preview_amd as G
+    kind, cfg = gl.model_zoo()[name]
+    cfg = dict(cfg, device=DEV)
+    cfg.pop("energy_guidance", None)
+    m = (G.IndependentConditionalFlowModel if kind == "icfm" else G.DiffusionModel)(cfg)
+    sd = {k: v for k, v in gu.weights(name).items() if k.startswith("model.")}
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    m.model.compute_dtype = L.BF16
+    return ("icfm" if kind == "icfm" else "diffusion"), cfg, m, sd
+
+
+@pytest.mark.parametrize("name,rows,steps", [("qgpo_noise", 1000, 100), ("icfm_cond", 300, 100),
+                                             ("swiss_noise", 500, 100), ("qgpo_noise", 128 * 300 + 5, 10)])
+def test_bf16_ode_sampling_vs_oracle(name, rows, steps):
+    kind, cfg, m, sd = _bf16_model(name)
+    S = gu.cond_dim(cfg)
+    D = cfg["x_size"]
+    gen = torch.Generator().manual_seed(11)
+    x0 = torch.randn(rows, D, generator=gen)
+    cond = torch.randn(rows, S, generator=gen) if S else None
+    t_span = torch.linspace(0.0, 1.0, steps + 1)
+    kw = dict(t_span=t_span, x_0=x0.to(DEV))
+    if S:
+        kw["condition"] = cond.to(DEV)
+    got = m.sample(**kw).cpu()
+    chunk = slice(0, min(rows, 2048))  # the oracle is slow: check a prefix and the ragged tail
+    tail = slice(max(0, rows - 64), rows)
+    for sl in (chunk, tail):
+        want = O.sample_forward_process(sd, cfg, kind, t_span, x_0=x0[sl], condition=None if cond is None else cond[sl])[-1]
+        close(got[sl], want, tol=BF16_TOL, what="bf16 %s" % name)
+
+
+def test_bf16_trajectory_and_sde_vs_golden():
+    """swiss-roll net (unconditional): golden ODE trajectories and Euler-Maruyama with fixed increments."""
+    kind, cfg, m, sd = _bf16_model("swiss_noise")
+    s = gu.load("sample_swiss_noise.npz")
+    for key, Tn, bs, use_x0, gs in _cases(s):
+        kw = dict(t_span=torch.linspace(0.0, 1.0, Tn), batch_size=bs, x_0=cu(s["x0"]) if use_x0 else None)
+        if not use_x0:
+            um.fix_noise(m, cu(s["xT_T%d_b%s_x0" % (Tn, bs)]))
+        close(m.sample_forward_process(**kw), s[key], tol=BF16_TOL, what="bf16 " + key)
+    for Tn, dt in ((11, 0.1), (21, 0.05)):
+        um.fix_noise(m, cu(s["sde_T%d_xT" % Tn]))
+        out = m.sample_forward_process(t_span=torch.linspace(0.0, 1.0, Tn), batch_size=2,
+                                       solver_config=dict(type="SDESolver", args=dict(library="torchsde", dt=dt)),
+                                       noise_increments=cu(s["sde_T%d_dW" % Tn]))
+        close(out, s["sde_T%d" % Tn], tol=BF16_TOL, what="bf16 sde")
+
+
+def test_bf16_rejects_unsupported_shapes():
+    kind, cfg, m = um.build("small_vp_noise", DEV)
+    m.model.compute_dtype = L.BF16
+    with pytest.raises(L.GrlHipError, match="bf16"):
+        m.sample(t_span=torch.linspace(0, 1, 5), x_0=torch.zeros(4, 6, device=DEV), condition=torch.zeros(4, 17, device=DEV))
