@@ -51,7 +51,7 @@ def build_model(device):
     return m
 
 
-def cpu_baseline(model, rows=8192, chunk=4096):
+def cpu_baseline(model, rows=32768, chunk=4096):
     """The CPU oracle (port of the reference's torch path) on a bounded sample of the same workload:
     `rows` rows x 100 Euler steps, chunked at 4096 like the reference's generate_fake_action."""
     from oracle import grl_oracle as O
