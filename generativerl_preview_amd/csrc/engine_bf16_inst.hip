@@ -15,6 +15,6 @@ using CfgSel = CfgSwiss;
 #define B16_CAT2(a, b, c, d) a##b##c##d
 #define B16_CAT(a, b, c, d) B16_CAT2(a, b, c, d)
 void B16_CAT(b16_launch_v, B16_VARIANT, _e, B16_EXTRA)(b16::SampleArgs16& a, int blocks, hipStream_t st) {
-  hipLaunchKernelGGL((b16::k_sample_bf16<CfgSel, B16_NSLOT, B16_CF, (B16_EXTRA != 0)>), dim3(blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((b16::k_sample_bf16<CfgSel, B16_NSLOT, B16_CF, B16_P, (B16_EXTRA != 0)>), dim3(blocks), dim3(256), 0, st, a);
 }
 }  // namespace grlhip
