@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgrlhip.so")
+# GRLHIP_LIB: developer override used by the kernel A/B scripts (scripts/ab_*.sh)
+LIB_PATH = os.environ.get("GRLHIP_LIB") or os.path.join(_HERE, "libgrlhip.so")
 
 MAX_HIDDEN = 8
 F32, BF16 = 0, 1
