@@ -101,6 +101,8 @@ int grlhip_plan_create(const grlhip_net_desc* net, grlhip_plan** out_plan) {
   if (grlhip_device_available()) {
     int rc = upload(p->fwd, &p->d_fwd);
     if (rc == 0) rc = upload(p->grad, &p->d_grad);
+    if (rc == 0) rc = upload(p->train_fwd, &p->d_train_fwd);
+    if (rc == 0) rc = upload(p->train_bwd, &p->d_train_bwd);
     if (rc != 0) { delete p; return rc; }
   }
   bf16_plan_init(p, p->d_fwd != nullptr);
@@ -113,6 +115,8 @@ void grlhip_plan_destroy(grlhip_plan* plan) {
   if (plan->p) {
     if (plan->p->d_fwd) (void)hipFree(plan->p->d_fwd);
     if (plan->p->d_grad) (void)hipFree(plan->p->d_grad);
+    if (plan->p->d_train_fwd) (void)hipFree(plan->p->d_train_fwd);
+    if (plan->p->d_train_bwd) (void)hipFree(plan->p->d_train_bwd);
     bf16_plan_free(plan->p);
     delete plan->p;
   }
@@ -288,17 +292,40 @@ int grlhip_sample_sde(const grlhip_plan* plan, const void* packed, int dtype, co
 }
 
 size_t grlhip_loss_workspace_bytes(const grlhip_plan* plan, int64_t rows, int dtype) {
-  (void)plan; (void)rows; (void)dtype;
-  return 0;
+  if (!plan || !plan->p || rows <= 0 || dtype != GRLHIP_F32 || plan->p->train_fwd.empty()) return 0;
+  return (size_t)f32_blocks(rows) * 4 * plan->p->train_slab_features * 32 * sizeof(float);
 }
 
 int grlhip_loss_fwd_bwd(const grlhip_plan* plan, const void* packed, int dtype, const float* t, const float* x_t,
                         const float* cond, const float* alpha, const float* beta, const float* target,
                         const float* row_weight, float* loss_rows, float* grad_flat, int64_t rows, void* workspace,
                         size_t workspace_bytes, void* stream) {
-  (void)plan; (void)packed; (void)dtype; (void)t; (void)x_t; (void)cond; (void)alpha; (void)beta; (void)target;
-  (void)row_weight; (void)loss_rows; (void)grad_flat; (void)rows; (void)workspace; (void)workspace_bytes; (void)stream;
-  return fail(GRLHIP_ERR_UNSUPPORTED, "loss_fwd_bwd: not built yet");
+  if (int rc = check_ready(plan, packed)) return rc;
+  const Plan* p = plan->p;
+  if (p->desc.kind != GRLHIP_NET_RESNET || !p->d_train_fwd)
+    return fail(GRLHIP_ERR_UNSUPPORTED, "loss_fwd_bwd needs a RESNET plan");
+  if (p->desc.out_dim != p->desc.x_dim) return fail(GRLHIP_ERR_INVALID, "loss_fwd_bwd needs out_dim == x_dim");
+  if (dtype != GRLHIP_F32) return fail(GRLHIP_ERR_UNSUPPORTED, "loss_fwd_bwd: only GRLHIP_F32 is implemented");
+  if (rows <= 0) return 0;
+  if (!t || !x_t || !alpha || !beta || !target || !loss_rows) return fail(GRLHIP_ERR_INVALID, "null t/x_t/alpha/beta/target/loss_rows");
+  if ((p->desc.cond_dim > 0) != (cond != nullptr))
+    return fail(GRLHIP_ERR_INVALID, "condition pointer does not match the plan's cond_dim");
+  const size_t need = grlhip_loss_workspace_bytes(plan, rows, dtype);
+  if (!workspace || workspace_bytes < need) return fail(GRLHIP_ERR_WORKSPACE, "workspace too small: need " + std::to_string(need));
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(workspace, 0, need, st));
+  LossArgs a{};
+  a.net = net_args(p, packed, false, 0);
+  a.net.ops = (const Op*)p->d_train_fwd; a.net.n_ops = (int32_t)p->train_fwd.size();
+  a.net.temb_off = p->tr_temb; a.net.x_off = p->tr_x; a.net.c_off = p->tr_c; a.net.out_off = p->tr_out;
+  a.bwd = (const Op*)p->d_train_bwd; a.n_bwd = (int32_t)p->train_bwd.size();
+  a.gout_off = p->tr_gout; a.gtc_off = p->tr_gtc;
+  a.t = t; a.x_t = x_t; a.cond = cond; a.alpha = alpha; a.beta = beta; a.target = target; a.row_weight = row_weight;
+  a.loss_rows = loss_rows; a.grad = grad_flat; a.fourier_grad = 1;
+  a.rows = rows; a.workspace = (float*)workspace; a.slab_features = p->train_slab_features;
+  hipLaunchKernelGGL(k_loss_f32, dim3(f32_blocks(rows)), dim3(256), 0, st, a);
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
 
 }  // extern "C"

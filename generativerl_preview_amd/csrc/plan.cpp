@@ -4,6 +4,7 @@
 #include "plan.hpp"
 
 #include <algorithm>
+#include <map>
 
 namespace grlhip {
 namespace {
@@ -14,6 +15,7 @@ struct Builder {
   Plan* p;
   int32_t bump = 0;
   int64_t woff = 0;
+  std::map<std::string, int> by_name;  // linear layer name -> index into p->linears
 
   int32_t alloc(int32_t features) {  // even-sized so a K-pad feature stays inside the buffer (and zero)
     int32_t o = bump;
@@ -30,7 +32,9 @@ struct Builder {
   int add_linear_params(const std::string& name, int N, int K, bool bias = true) {
     int pw = add_param(name + ".weight", N, K);
     int pb = bias ? add_param(name + ".bias", N, 0) : -1;
-    return add_matrix(N, K, pw, pb, 0, K, 0);
+    int l = add_matrix(N, K, pw, pb, 0, K, 0);
+    by_name[name] = l;
+    return l;
   }
   int add_matrix(int N, int K, int pw, int pb, int col0, int src_cols, int transposed) {
     LinearDesc l{};
@@ -127,6 +131,120 @@ Plan* build_plan(const grlhip_net_desc& d, std::string& err) {
     }
     int ll = b.add_linear_params("backbone.last_block", d.out_dim, 2 * h[0]);
     b.linear(F, ll, cat[0], p->out_off, -1, 0);
+
+    // ------------------------------------------------------------------ training step programs
+    // Own slab layout (every pre-activation kept, gradient buffers appended); weights W^T are packed
+    // as extra matrices so that dX = W^T dZ is the same LINEAR op.
+    {
+      Builder t{p};
+      t.woff = b.woff;
+      auto& TF = p->train_fwd;
+      auto& TB = p->train_bwd;
+      auto T_of = [&](int lin) {  // transposed copy of a packed linear
+        const LinearDesc l = p->linears[lin];
+        return t.add_matrix(l.K, l.N, l.p_w, -1, 0, l.K, 1);
+      };
+      auto dw = [&](int lin, int dz, int in) {  // weight + bias gradient of a linear
+        const LinearDesc l = p->linears[lin];
+        Op o{};
+        o.type = OP_DW; o.K = l.K; o.N = l.N; o.w = (int32_t)p->params[l.p_w].grad_off;
+        o.b = l.p_b >= 0 ? (int32_t)p->params[l.p_b].grad_off : -1;
+        o.in = in; o.add = dz; o.out = -1; o.pre = l.K; o.lin = lin;
+        TB.push_back(o);
+      };
+      auto lin_t = [&](int lin, int in, int out, bool accum) { t.linear(TB, T_of(lin), in, out, -1, accum ? F_ACCUM : 0); };
+      const int L_ = L;
+      p->tr_temb = t.alloc(d.t_dim + ch);
+      const int tc = p->tr_temb, cemb_t = tc + d.t_dim;
+      p->tr_x = t.alloc(d.x_dim);
+      p->tr_c = cond ? t.alloc(d.cond_dim) : -1;
+      const int zc = cond ? t.alloc(ch) : -1;
+      const int z0 = t.alloc(tch), a0 = t.alloc(tch), te_t = t.alloc(tch), ste_t = t.alloc(tch);
+      std::vector<int> catf(L_), gcat(L_);
+      for (int i = 0; i < L_; ++i) catf[i] = t.alloc(2 * h[i]);
+      p->tr_out = t.alloc(d.out_dim);
+      // gradient buffers
+      p->tr_gout = t.alloc(d.out_dim);
+      for (int i = 0; i < L_; ++i) gcat[i] = t.alloc(2 * h[i]);
+      const int g_ste = t.alloc(tch), g_te = t.alloc(tch), g_a0 = t.alloc(tch), g_z0 = t.alloc(tch);
+      p->tr_gtc = t.alloc(d.t_dim + ch);
+      const int g_zc = cond ? t.alloc(ch) : -1;
+      const int hmax_t = *std::max_element(h, h + L_);
+      const int g_h1 = t.alloc(hmax_t), g_z = t.alloc(hmax_t), sM = t.alloc(hmax_t);
+
+      struct Blk { int lt, l1, ld, lm, in, K, out, N, T, z1, h1, z2; };
+      std::vector<Blk> blks;
+      auto fblock = [&](const std::string& name, int in, int K, int out, int N) {
+        Blk k{};
+        k.lt = b.by_name[name + ".time_mlp.1"]; k.l1 = b.by_name[name + ".dense1.0"]; k.ld = b.by_name[name + ".dense2.0"];
+        k.lm = (K != N) ? b.by_name[name + ".modify_x"] : -1;
+        k.in = in; k.K = K; k.out = out; k.N = N;
+        k.T = t.alloc(N); k.z1 = t.alloc(N); k.h1 = t.alloc(N); k.z2 = t.alloc(N);
+        t.linear(TF, k.lt, ste_t, k.T, -1, 0);
+        t.linear(TF, k.l1, in, k.h1, k.T, F_SILU_OUT | F_SAVE_PRE, k.z1);
+        int res = in;
+        if (k.lm >= 0) { t.linear(TF, k.lm, in, sM, -1, 0); res = sM; }
+        t.linear(TF, k.ld, k.h1, out, res, F_SILU_OUT | F_SAVE_PRE, k.z2);
+        blks.push_back(k);
+      };
+      if (cond) t.linear(TF, b.by_name["backbone.pre_sort_condition.0"], p->tr_c, cemb_t, -1, F_SILU_OUT | F_SAVE_PRE, zc);
+      t.linear(TF, b.by_name["backbone.sort_t.0"], tc, a0, -1, F_SILU_OUT | F_SAVE_PRE, z0);
+      t.linear(TF, b.by_name["backbone.sort_t.2"], a0, te_t, -1, 0);
+      t.eltwise(TF, OP_SILU, tch, te_t, ste_t);
+      fblock("backbone.first_block", p->tr_x, d.x_dim, catf[0] + h[0], h[0]);
+      for (int i = 0; i + 1 < L_; ++i)
+        fblock("backbone.down_block." + std::to_string(i), catf[i] + h[i], h[i], catf[i + 1] + h[i + 1], h[i + 1]);
+      fblock("backbone.middle_block", catf[L_ - 1] + h[L_ - 1], h[L_ - 1], catf[L_ - 1], h[L_ - 1]);
+      for (int j = 0; j + 1 < L_; ++j) {
+        int i = L_ - 2 - j;
+        fblock("backbone.up_block." + std::to_string(j), catf[i + 1], h[i], catf[i], h[i]);
+      }
+      t.linear(TF, b.by_name["backbone.last_block"], catf[0], p->tr_out, -1, 0);
+
+      // ---- backward.  gin_mode: 0 = input gradient not needed, 1 = write, 2 = accumulate
+      bool ste_written = false;
+      auto bblock = [&](const Blk& k, int gout, int gin, int gin_mode) {
+        if (k.lm >= 0) {
+          dw(k.lm, gout, k.in);
+          if (gin_mode) lin_t(k.lm, gout, gin, gin_mode == 2);
+        } else if (gin_mode) {
+          t.eltwise(TB, gin_mode == 2 ? OP_ADD : OP_COPY, k.N, gout, gin);
+        }
+        t.eltwise(TB, OP_SILU_BWD, k.N, k.z2, g_z, gout);       // dz2 = dout * silu'(z2)
+        dw(k.ld, g_z, k.h1);
+        lin_t(k.ld, g_z, g_h1, false);                            // dh1 (= dT)
+        dw(k.lt, g_h1, ste_t);
+        lin_t(k.lt, g_h1, g_ste, ste_written);
+        ste_written = true;
+        t.eltwise(TB, OP_SILU_BWD, k.N, k.z1, g_z, g_h1);        // dz1 = dh1 * silu'(z1)
+        dw(k.l1, g_z, k.in);
+        if (gin_mode) lin_t(k.l1, g_z, gin, true);
+      };
+      const int llast = b.by_name["backbone.last_block"];
+      dw(llast, p->tr_gout, catf[0]);
+      lin_t(llast, p->tr_gout, gcat[0], false);
+      int bi = (int)blks.size() - 1;                              // blocks were pushed in forward order
+      for (int j = L_ - 2; j >= 0; --j, --bi) {                    // up blocks, reversed
+        int i = L_ - 2 - j;
+        bblock(blks[bi], gcat[i], gcat[i + 1], 1);
+      }
+      bblock(blks[bi], gcat[L_ - 1], gcat[L_ - 1] + h[L_ - 1], 2); --bi;   // middle
+      for (int i = L_ - 2; i >= 0; --i, --bi)                      // down blocks, reversed
+        bblock(blks[bi], gcat[i + 1] + h[i + 1], gcat[i] + h[i], 2);
+      bblock(blks[bi], gcat[0] + h[0], -1, 0);                     // first block (no dx)
+      t.eltwise(TB, OP_SILU_BWD, tch, te_t, g_te, g_ste);          // ste = silu(te)
+      dw(b.by_name["backbone.sort_t.2"], g_te, a0);
+      lin_t(b.by_name["backbone.sort_t.2"], g_te, g_a0, false);
+      t.eltwise(TB, OP_SILU_BWD, tch, z0, g_z0, g_a0);
+      dw(b.by_name["backbone.sort_t.0"], g_z0, tc);
+      lin_t(b.by_name["backbone.sort_t.0"], g_z0, p->tr_gtc, false);   // d[t_emb | c_emb]
+      if (cond) {
+        t.eltwise(TB, OP_SILU_BWD, ch, zc, g_zc, p->tr_gtc + d.t_dim);
+        dw(b.by_name["backbone.pre_sort_condition.0"], g_zc, p->tr_c);
+      }
+      p->train_slab_features = up(t.bump, 2);
+      b.woff = t.woff;
+    }
   } else if (d.kind == GRLHIP_NET_CONCAT_MLP) {
     const int L = d.n_hidden;
     const int K0 = d.t_dim + d.x_dim + d.cond_dim;

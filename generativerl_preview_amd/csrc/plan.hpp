@@ -21,9 +21,11 @@ enum OpType : int32_t {
   OP_SILU = 1,           // out[n] = silu(in[n])
   OP_COPY = 2,           // out[n] = in[n]
   OP_SILU_BWD = 3,       // out[n] = slab[add + n] * silu'(in[n])
-  OP_SILU_BWD_CONST = 4  // out[n] = wts[w + n] * silu'(in[n])
+  OP_SILU_BWD_CONST = 4, // out[n] = wts[w + n] * silu'(in[n])
+  OP_DW = 5,             // grad[w + n*pre + k] += sum_rows slab[add + n] * slab[in + k]; grad[b + n] += sum_rows slab[add + n]
+  OP_ADD = 6             // out[n] += in[n]
 };
-enum OpFlags : int32_t { F_SILU_OUT = 1, F_SAVE_PRE = 2 };
+enum OpFlags : int32_t { F_SILU_OUT = 1, F_SAVE_PRE = 2, F_ACCUM = 4 };
 
 struct Op {
   int32_t type, K, N, w, b, in, out, add, flags, pre;  // pre: where z (pre-activation) is kept (F_SAVE_PRE)
@@ -53,6 +55,12 @@ struct Plan {
   std::vector<LinearDesc> linears;
   std::vector<Op> fwd;       // forward program
   std::vector<Op> grad;      // CONCAT_MLP only: forward (pre-activations) + backward to x
+  // RESNET training step: forward keeping every pre-activation, then the backward program
+  std::vector<Op> train_fwd, train_bwd;
+  int32_t train_slab_features = 0;
+  int32_t tr_temb = 0, tr_x = 0, tr_c = -1, tr_out = 0, tr_gout = 0, tr_gtc = 0;
+  void* d_train_fwd = nullptr;
+  void* d_train_bwd = nullptr;
   int32_t slab_features = 0;
   int32_t temb_off = 0, x_off = 0, c_off = 0, out_off = 0, gradx_off = 0;
   int64_t fourier_off = 0;   // offset of W (t_dim/2 floats) in the fp32 image

@@ -210,3 +210,92 @@ def test_bf16_rejects_unsupported_shapes():
     m.model.compute_dtype = L.BF16
     with pytest.raises(L.GrlHipError, match="bf16"):
         m.sample(t_span=torch.linspace(0, 1, 5), x_0=torch.zeros(4, 6, device=DEV), condition=torch.zeros(4, 17, device=DEV))
+
+
+# ----------------------------------------------------------------------------- fused training step
+def _check_grads(m, g, pfx):
+    n = 0
+    for k, p in m.named_parameters():
+        if not k.startswith("model.") or k.endswith("t_encoder.W"):
+            continue
+        assert p.grad is not None, k
+        if pfx + "_grad/" + k in g:
+            close(p.grad, g[pfx + "_grad/" + k], tol=2e-4, what=pfx + " grad " + k)
+            n += 1
+        elif pfx + "_gradsub/" + k in g:
+            flat = p.grad.reshape(-1)
+            close(flat[:: max(1, flat.numel() // 509)][:509], g[pfx + "_gradsub/" + k], tol=2e-4, what=pfx + " grad " + k)
+            s = g[pfx + "_gradsum/" + k]
+            assert abs(float(flat.double().pow(2).sum().sqrt()) - s[1]) <= 2e-4 * s[1] + 1e-7, k
+            n += 1
+    assert n > 10
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_losses_and_grads_vs_golden(name):
+    """score_matching_loss / flow_matching_loss forward + backward: loss within 1e-5 relative
+    (north_star), per-row losses and every parameter gradient against the reference's autograd."""
+    kind, cfg, m = um.build(name, DEV)
+    g = gu.load("model_%s.npz" % name)
+    x, cond = cu(g["x"]), cu(g.get("cond"))
+    cases = []
+    if kind == "icfm":
+        cases.append(("fm", lambda avg: m.flow_matching_loss(cu(g["eps"]), x, cond, average=avg, t=cu(g["fm_t"]), noise=cu(g["fm_eps"]))))
+    else:
+        if "sm_loss" in g:
+            cases.append(("sm", lambda avg: m.score_matching_loss(x, cond, weighting_scheme="vanilla", average=avg,
+                                                                  t=cu(g["sm_t"]), noise=cu(g["sm_eps"]))))
+        if "fm_loss" in g:
+            cases.append(("fm", lambda avg: m.flow_matching_loss(x, cond, average=avg, t=cu(g["fm_t"]), noise=cu(g["fm_eps"]))))
+    assert cases
+    for pfx, call in cases:
+        m.zero_grad(set_to_none=True)
+        loss = call(True)
+        want = float(g[pfx + "_loss"])
+        assert abs(float(loss) - want) <= 1e-5 * abs(want) + 1e-7, (pfx, float(loss), want)
+        loss.backward()
+        _check_grads(m, g, pfx)
+        rows = call(False)
+        close(rows, g[pfx + "_loss_rows"], tol=2e-5, what=pfx + " rows")
+
+
+def test_weighted_rows_backward_and_trainable_fourier():
+    """average=False + per-row weights (the GMPO weighted-loss pattern) and a trainable Fourier W
+    (swiss-roll tutorial) against torch autograd on the CPU oracle."""
+    name = "small_vp_noise"
+    kind, cfg, m = um.build(name, DEV)
+    m.model.model["t_encoder"].W.requires_grad_(True)
+    g = gu.load("model_%s.npz" % name)
+    x, cond, t, eps = cu(g["x"]), cu(g["cond"]), cu(g["sm_t"]), cu(g["sm_eps"])
+    w = torch.linspace(0.1, 2.0, x.shape[0])
+    rows = m.score_matching_loss(x, cond, weighting_scheme="vanilla", average=False, t=t, noise=eps)
+    (rows * w.to(DEV)).sum().backward()
+    sd = gu.weights(name)
+    keys = [k for k in sd if k.startswith("model.")]
+    for k in keys:
+        sd[k].requires_grad_(True)
+    fn = lambda tt, y: O.intrinsic_forward(sd, tt, y, gu.T(g["cond"]))  # noqa: E731
+    ref = O.score_matching_loss(cfg["model"]["type"], O.Path(cfg["path"]), fn, gu.T(g["x"]), gu.T(g["sm_t"]),
+                                gu.T(g["sm_eps"]), average=False)
+    grads = dict(zip(keys, torch.autograd.grad((ref * w).sum(), [sd[k] for k in keys])))
+    for k, p in m.named_parameters():
+        if k.startswith("model."):
+            close(p.grad, grads[k], tol=3e-4, what=k)
+
+
+def test_adam_step_moves_the_loss_down():
+    kind, cfg, m = um.build("small_icfm", DEV)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    gen = torch.Generator().manual_seed(3)
+    x1 = torch.rand(256, 6, generator=gen).mul(2).sub(1).to(DEV)
+    cond = torch.randn(256, 17, generator=gen).to(DEV)
+    x0, t, eps = torch.randn(256, 6, generator=gen).to(DEV), torch.rand(256, generator=gen).to(DEV), torch.randn(256, 6, generator=gen).to(DEV)
+    losses = []
+    for _ in range(20):
+        opt.zero_grad()
+        loss = m.flow_matching_loss(x0, x1, cond, t=t, noise=eps)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < 0.9 * losses[0] and all(b < a for a, b in zip(losses, losses[1:])), losses
