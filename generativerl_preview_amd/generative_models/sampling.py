@@ -53,7 +53,7 @@ def reshape_output(model, data, batch_size, extra, n, x_0, condition):
     """(T, B*N, D) -> (T, *B, N, D) + the reference's squeezes.  Rows were laid out n*B+b by
     repeat_interleave but are read here as b*N+n -- kept as written."""
     xs = (model.x_size,) if isinstance(model.x_size, int) else tuple(model.x_size)
-    data = data.reshape(-1, *extra, n, *xs)
+    data = data.reshape(data.shape[0], *extra, n, *xs)
     if batch_size is None:
         data = data.squeeze(1).squeeze(1) if (x_0 is None and condition is None) else data.squeeze(1)
     elif x_0 is None and condition is None:
