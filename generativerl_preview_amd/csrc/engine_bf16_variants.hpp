@@ -3,5 +3,10 @@
 namespace grlhip {
 using CfgQgpo = b16::Cfg<6, 17, 32, 32, 128, 512, 256, 128>;  // QGPO / GMPO HalfCheetah: act 6, obs 17
 using CfgSwiss = b16::Cfg<2, 0, 0, 32, 32, 512, 256, 128>;    // swiss-roll tutorial: D = 2, unconditional
-constexpr int B16_NSLOT = 4, B16_CF = 16, B16_P = 8;  // ring slots, fragments per chunk, register prefetch depth
+#ifndef B16_NSLOT_V
+#define B16_NSLOT_V 4
+#define B16_CF_V 16
+#define B16_P_V 8
+#endif
+constexpr int B16_NSLOT = B16_NSLOT_V, B16_CF = B16_CF_V, B16_P = B16_P_V;  // ring slots, fragments per chunk, register prefetch depth
 }  // namespace grlhip
