@@ -82,9 +82,14 @@ class FusedDrift:
                 return tau, -(f + D), p.scale(tau) * D, zero, s
         raise NotImplementedError("Unknown type of function {}".format(mt))
 
-    def table(self, t_steps, dts, emit, lerp):
+    def table(self, t_steps, dts, emit, lerp, emit2=None, lerp2=None):
         tau, a, b, g, s = self.coefficients(t_steps)
-        tab = torch.stack([tau, dts.to(torch.float32), a, b, g, s, emit.to(torch.float32), lerp.to(torch.float32)], 1)
+        n = len(t_steps)
+        emit2 = torch.full((n,), -1.0) if emit2 is None else emit2.to(torch.float32)
+        lerp2 = torch.ones(n) if lerp2 is None else lerp2.to(torch.float32)
+        zero = torch.zeros(n)
+        tab = torch.stack([tau, dts.to(torch.float32), a, b, g, s, emit.to(torch.float32), lerp.to(torch.float32),
+                           emit2, lerp2, zero, zero], 1)
         assert tab.shape[1] == L.COEF_STRIDE
         return tab.contiguous()
 

@@ -25,27 +25,43 @@ class SDESolver:
         self.library = library
 
     def _schedule(self, t_span):
+        """torchsde's stepping, tabulated: inner steps (t0, dt) and, per requested output k >= 1, the
+        step that brackets it and the interpolation weight w (out = y_prev + w (y_new - y_prev))."""
         ts = t_span.detach().to("cpu", torch.float32)
         dt = torch.as_tensor(self.dt, dtype=ts.dtype)
-        t0s, dts, emit, lerp = [], [], [], []
+        t0s, dts, outs = [], [], []   # outs: (output slot, step index, w)
         curr, prev = ts[0], ts[0]
         for k in range(1, len(ts)):
             out_t = ts[k]
-            stepped = False
             while curr < out_t:
                 nxt = torch.minimum(curr + dt, ts[-1])
                 t0s.append(curr)
                 dts.append(nxt - curr)
-                emit.append(-1)
-                lerp.append(1.0)
                 prev, curr = curr, nxt
-                stepped = True
-            if not stepped:
-                raise NotImplementedError("t_span spacing below the solver dt (several outputs inside one "
-                                          "Euler-Maruyama step) is not supported; use dt <= min spacing")
-            emit[-1] = k
-            lerp[-1] = 1.0 if (curr == out_t or prev == curr) else float((out_t - prev) / (curr - prev))
-        return torch.stack(t0s), torch.stack(dts), torch.tensor(emit), torch.tensor(lerp)
+            if not t0s:
+                raise ValueError("t_span must be increasing")
+            w = 1.0 if (curr == out_t or prev == curr) else float((out_t - prev) / (curr - prev))
+            outs.append((k, len(t0s) - 1, w))
+        return torch.stack(t0s), torch.stack(dts), outs
+
+    @staticmethod
+    def _emit_plan(n_steps, outs):
+        """The kernel emits at most two states per step; further outputs bracketed by the same step are
+        linear in those two and are filled in afterwards (`extra`: (slot, slotA, slotB, coefficient))."""
+        emit, lerp = torch.full((n_steps,), -1.0), torch.ones(n_steps)
+        emit2, lerp2 = torch.full((n_steps,), -1.0), torch.ones(n_steps)
+        by_step = {}
+        for k, s, w in outs:
+            by_step.setdefault(s, []).append((k, w))
+        extra = []
+        for s, lst in by_step.items():
+            emit[s], lerp[s] = lst[0]
+            if len(lst) > 1:
+                emit2[s], lerp2[s] = lst[-1]
+                (ka, wa), (kb, wb) = lst[0], lst[-1]
+                for k, w in lst[1:-1]:
+                    extra.append((k, ka, kb, 0.0 if wb == wa else (w - wa) / (wb - wa)))
+        return emit, lerp, emit2, lerp2, extra
 
     def integrate(self, drift, diffusion, x0, t_span, logqp=False, adaptive=False, noise_increments=None,
                   return_trajectory=True):
@@ -53,8 +69,9 @@ class SDESolver:
             raise NotImplementedError("only the fixed-step diagonal-Ito Euler-Maruyama scheme is implemented")
         if not isinstance(drift, FusedDrift):
             raise NotImplementedError("SDESolver integrates the reverse SDEs built by DiffusionProcess.reverse_sde")
-        t0s, dts, emit, lerp = self._schedule(t_span)
+        t0s, dts, outs = self._schedule(t_span)
         n = len(t0s)
+        emit, lerp, emit2, lerp2, extra = self._emit_plan(n, outs)
         B = x0.shape[0]
         flat = x0.reshape(B, -1)
         if noise_increments is None:
@@ -64,10 +81,12 @@ class SDESolver:
                                                 for k in range(n)])
             else:
                 noise_increments = torch.randn(n, *flat.shape, device=flat.device) * dts.sqrt().to(flat.device)[:, None, None]
-        table = drift.table(t0s, dts, emit, lerp)
+        table = drift.table(t0s, dts, emit, lerp, emit2, lerp2)
         final, traj = drift.integrate(flat, table, noise_increments.reshape(n, B, -1),
                                       trajectory_slots=len(t_span) if return_trajectory else 0)
         self.nfe_drift = self.nfe_diffusion = n
         if not return_trajectory:
             return final.reshape(x0.shape)
+        for k, ka, kb, c in extra:
+            traj[k] = traj[ka] + c * (traj[kb] - traj[ka])
         return traj.reshape(t_span.shape[0], *x0.shape)

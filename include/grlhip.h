@@ -101,7 +101,7 @@ int grlhip_energy_grad(const grlhip_plan* plan, const void* packed, int dtype, c
                        const float* x, const float* cond, float scale, float* grad, int64_t rows,
                        void* workspace, size_t workspace_bytes, void* stream);
 
-/* Per-step coefficients of the fused integrator, a HOST-computed DEVICE table coef[n_steps][8]:
+/* Per-step coefficients of the fused integrator, a HOST-computed DEVICE table coef[n_steps][GRLHIP_COEF_STRIDE]:
  *   [0] tau    time fed to the network at this step
  *   [1] dt     step length
  *   [2] a      x_{k+1} = x_k + dt * (a*x_k + b*net(tau,x_k,c) + g*dE/dx(tau,x_k,c)) + s*dW_k
@@ -112,10 +112,13 @@ int grlhip_energy_grad(const grlhip_plan* plan, const void* packed, int dtype, c
  *              stored as float
  *   [7] lerp   weight w for the emitted state: out = x_prev + w*(x_new - x_prev) (1 = x_new),
  *              reproducing torchsde's interpolation to requested output times.
+ *   [8] emit2, [9] lerp2   a second emission of the same step (emit2 < 0: none); when a step spans
+ *              more than two requested output times the caller interpolates the rest from these two.
+ *   [10], [11] reserved (0).
  * This covers every (model head x path x solver) closure of DiffusionProcess.reverse_ode / reverse_sde
  * (grl/generative_models/diffusion_process.py:742-919) and the ICFM drift
  * (conditional_flow_model/independent_conditional_flow_model.py:285-288). */
-#define GRLHIP_COEF_STRIDE 8
+#define GRLHIP_COEF_STRIDE 12
 
 /* Replaces: ODESolver.integrate with Euler on the caller's grid
  * (grl/numerical_methods/numerical_solvers/ode_solver.py:51-79,168-185) driven from

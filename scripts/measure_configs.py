@@ -55,11 +55,13 @@ report("C3 ICFM flow_matching_loss fwd+bwd+Adam, batch 65536", engine="f32", sec
 q = G.EnergyConditionalDiffusionModel(dict(gl.diffusion_cfg(6, gl.VP, "noise_function", [512, 256, 128], 17, energy=True), device=DEV)).to(DEV)
 R = 1 << 18
 cond = torch.randn(R, 17, device=DEV); x0 = torch.randn(R, 6, device=DEV)
-dW = torch.randn(100, R, 6, device=DEV) * 0.1
+from generativerl_preview_amd.numerical_methods.numerical_solvers import SDESolver
+n_inner = len(SDESolver(dt=0.01)._schedule(ts)[0])   # 100 or 101: fp32 accumulation of dt vs linspace
+dW = torch.randn(n_inner, R, 6, device=DEV) * 0.1
 t = timed(lambda: q.sample(t_span=ts, x_0=x0, condition=cond, guidance_scale=1.0, noise_increments=dW,
                            solver_config=dict(type="SDESolver", args=dict(dt=0.01))), 1)
-report("C4 QGPO guided Euler-Maruyama 100 steps, %d rows" % R, engine="f32", seconds=t, action_steps_per_s=R * 100 / t,
-       tflops=R * 100 * 3547712 / t / 1e12)
+report("C4 QGPO guided Euler-Maruyama %d steps, %d rows" % (n_inner, R), engine="f32", seconds=t,
+       action_steps_per_s=R * n_inner / t, tflops=R * n_inner * 3547712 / t / 1e12)
 
 # C5: GVP velocity net, D = 64, hidden [1024], batch 262144, 100-step ODE
 g5 = G.DiffusionModel(dict(gl.diffusion_cfg(64, gl.GVP, "velocity_function", [1024]), device=DEV)).to(DEV)

@@ -117,13 +117,20 @@ def test_coefficient_table_reproduces_the_drift_closures(mt, pcfg, kind):
 
 def test_sde_schedule_matches_torchsde_semantics():
     s = SDESolver(dt=0.03)
-    t0, dts, emit, lerp = s._schedule(torch.linspace(0, 1, 11))
+    t0, dts, outs = s._schedule(torch.linspace(0, 1, 11))
     assert abs(float(dts.sum()) - 1.0) < 1e-5
-    assert sorted(e for e in emit.tolist() if e >= 0) == list(range(1, 11))
-    assert float(lerp.min()) > 0 and float(lerp.max()) <= 1.0
+    assert [k for k, _, _ in outs] == list(range(1, 11))
+    assert all(0 < w <= 1.0 for _, _, w in outs)
     # grid == dt: one step per output, no interpolation
-    t0, dts, emit, lerp = SDESolver(dt=0.1)._schedule(torch.linspace(0, 1, 11))
-    assert len(t0) == 10 and emit.tolist() == list(range(1, 11))
+    t0, dts, outs = SDESolver(dt=0.1)._schedule(torch.linspace(0, 1, 11))
+    assert len(t0) == 10 and [st for _, st, _ in outs] == list(range(10))
+    # dt larger than the spacing: several outputs bracketed by one step -> two emits + host interpolation
+    t0, dts, outs = SDESolver(dt=0.35)._schedule(torch.linspace(0, 1, 11))
+    emit, lerp, emit2, lerp2, extra = SDESolver._emit_plan(len(t0), outs)
+    assert len(t0) == 3 and int((emit2 >= 0).sum()) == 3 and len(extra) == 10 - 6
+    # fp32 round-off case of the C4 config (dt = 1/100 on linspace(0, 1, 101)) must tabulate
+    t0, dts, outs = SDESolver(dt=0.01)._schedule(torch.linspace(0, 1, 101))
+    assert len(outs) == 100
 
 
 def test_monte_carlo_sampler_matches_golden():
