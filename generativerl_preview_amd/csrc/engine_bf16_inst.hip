@@ -1,5 +1,6 @@
-// One (variant, EXTRA) instantiation of the bf16 persistent integrator per translation unit, so
-// the four ~1 minute device compilations run in parallel.  Built with -DB16_VARIANT=0|1 -DB16_EXTRA=0|1.
+// One (variant, EXTRA, guided) instantiation of the bf16 persistent integrator per translation unit,
+// so the ~1 minute device compilations run in parallel.
+// Built with -DB16_VARIANT=0|1 -DB16_EXTRA=0|1 -DB16_GUIDE=0|1.
 #include <hip/hip_runtime.h>
 
 #include "plan.hpp"
@@ -12,9 +13,14 @@ using CfgSel = CfgQgpo;
 #else
 using CfgSel = CfgSwiss;
 #endif
-#define B16_CAT2(a, b, c, d) a##b##c##d
-#define B16_CAT(a, b, c, d) B16_CAT2(a, b, c, d)
-void B16_CAT(b16_launch_v, B16_VARIANT, _e, B16_EXTRA)(b16::SampleArgs16& a, int blocks, hipStream_t st) {
-  hipLaunchKernelGGL((b16::k_sample_bf16<CfgSel, B16_NSLOT, B16_CF, B16_P, (B16_EXTRA != 0)>), dim3(blocks), dim3(256), 0, st, a);
+#if B16_GUIDE == 0
+using GuideSel = b16::NoGuide;
+#else
+using GuideSel = GuideQgpo;
+#endif
+#define B16_CAT2(a, b, c, d, e, f) a##b##c##d##e##f
+#define B16_CAT(a, b, c, d, e, f) B16_CAT2(a, b, c, d, e, f)
+void B16_CAT(b16_launch_v, B16_VARIANT, _e, B16_EXTRA, _g, B16_GUIDE)(b16::SampleArgs16& a, int blocks, hipStream_t st) {
+  hipLaunchKernelGGL((b16::k_sample_bf16<CfgSel, GuideSel, B16_NSLOT, B16_CF, B16_P, (B16_EXTRA != 0)>), dim3(blocks), dim3(256), 0, st, a);
 }
 }  // namespace grlhip

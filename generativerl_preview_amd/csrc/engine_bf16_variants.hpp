@@ -3,6 +3,7 @@
 namespace grlhip {
 using CfgQgpo = b16::Cfg<6, 17, 32, 32, 128, 512, 256, 128>;  // QGPO / GMPO HalfCheetah: act 6, obs 17
 using CfgSwiss = b16::Cfg<2, 0, 0, 32, 32, 512, 256, 128>;    // swiss-roll tutorial: D = 2, unconditional
+using GuideQgpo = b16::GuideCfg<32, 256, 256>;                // QGPO energy net: ConcatenateMLP [55, 256, 256] -> 1
 #ifndef B16_NSLOT_V
 #define B16_NSLOT_V 4
 #define B16_CF_V 16

@@ -1,0 +1,33 @@
+"""C4 on the bf16 engine: QGPO net + fused energy guidance, guided ODE and guided Euler-Maruyama."""
+import json, sys, time, torch
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests/golden')
+import golden_lib as gl
+import generativerl_preview_amd as G
+from generativerl_preview_amd import _lib as L
+from generativerl_preview_amd.numerical_methods.numerical_solvers import SDESolver
+DEV = "cuda:0"
+
+
+def timed(fn, n=2):
+    fn(); torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.time() - t0) / n
+
+
+ts = torch.linspace(0, 1, 101)
+q = G.EnergyConditionalDiffusionModel(dict(gl.diffusion_cfg(6, gl.VP, "noise_function", [512, 256, 128], 17, energy=True), device=DEV)).to(DEV)
+q.model.compute_dtype = L.BF16
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 21
+cond = torch.randn(R, 17, device=DEV); x0 = torch.randn(R, 6, device=DEV)
+t = timed(lambda: q.sample(t_span=ts, x_0=x0, condition=cond, guidance_scale=1.0))
+print(json.dumps(dict(config="C4 QGPO guided ODE 100 steps, %d rows" % R, engine="bf16", seconds=t,
+                      action_steps_per_s=R * 100 / t, tflops=R * 100 * 3547712 / t / 1e12)), flush=True)
+n_inner = len(SDESolver(dt=0.01)._schedule(ts)[0])
+dW = torch.randn(n_inner, R, 6, device=DEV) * 0.1
+t = timed(lambda: q.sample(t_span=ts, x_0=x0, condition=cond, guidance_scale=1.0, noise_increments=dW,
+                           solver_config=dict(type="SDESolver", args=dict(dt=0.01))))
+print(json.dumps(dict(config="C4 QGPO guided Euler-Maruyama %d steps, %d rows" % (n_inner, R), engine="bf16", seconds=t,
+                      action_steps_per_s=R * n_inner / t, tflops=R * n_inner * 3547712 / t / 1e12)), flush=True)

@@ -205,6 +205,55 @@ def test_bf16_trajectory_and_sde_vs_golden():
         close(out, s["sde_T%d" % Tn], tol=BF16_TOL, what="bf16 sde")
 
 
+def _bf16_energy_model():
+    kind, cfg, m = um.build("qgpo_noise", DEV)
+    m.model.compute_dtype = L.BF16
+    return cfg, m, gu.weights("qgpo_noise")
+
+
+def test_bf16_guided_sampling_vs_golden():
+    """QGPO net + energy net fused in the bf16 integrator: guided ODE trajectories (every batch_size / x_0
+    combination, guidance_scale 0 and 1) and guided Euler-Maruyama with the golden increments."""
+    cfg, m, sd = _bf16_energy_model()
+    s = gu.load("sample_qgpo_noise.npz")
+    n = 0
+    for key, Tn, bs, use_x0, gs in _cases(s):
+        kw = dict(t_span=torch.linspace(0.0, 1.0, Tn), batch_size=bs, x_0=cu(s["x0"]) if use_x0 else None,
+                  condition=cu(s["cond"]), guidance_scale=gs)
+        if not use_x0:
+            um.fix_noise(m, cu(s["xT_T%d_b%s_x0" % (Tn, bs)]))
+        close(m.sample_forward_process(**kw), s[key], tol=BF16_TOL, what="bf16 guided " + key)
+        close(m.sample(**kw), s[key][-1], tol=BF16_TOL, what="bf16 guided final " + key)
+        n += 1
+    assert n >= 8
+    for Tn, dt in ((11, 0.1), (21, 0.05)):
+        for gs in (0, 1):
+            um.fix_noise(m, cu(s["sde_T%d_xT" % Tn]))
+            out = m.sample_forward_process(t_span=torch.linspace(0.0, 1.0, Tn), batch_size=2, condition=cu(s["cond"]),
+                                           guidance_scale=float(gs),
+                                           solver_config=dict(type="SDESolver", args=dict(library="torchsde", dt=dt)),
+                                           noise_increments=cu(s["sde_T%d_dW" % Tn]))
+            close(out, s["sde_T%d_g%d" % (Tn, gs)], tol=BF16_TOL, what="bf16 guided sde")
+
+
+@pytest.mark.parametrize("rows,steps,scale", [(1000, 100, 1.0), (128 * 260 + 37, 10, 3.0)])
+def test_bf16_guided_ode_vs_oracle(rows, steps, scale):
+    cfg, m, sd = _bf16_energy_model()
+    gen = torch.Generator().manual_seed(23)
+    x0 = torch.randn(rows, 6, generator=gen)
+    cond = torch.randn(rows, 17, generator=gen)
+    t_span = torch.linspace(0.0, 1.0, steps + 1)
+    got = m.sample(t_span=t_span, x_0=x0.to(DEV), condition=cond.to(DEV), guidance_scale=scale).cpu()
+    ref32 = None
+    for sl in (slice(0, min(rows, 1024)), slice(max(0, rows - 64), rows)):
+        want = O.sample_forward_process(sd, cfg, "energy", t_span, x_0=x0[sl], condition=cond[sl], guidance_scale=scale)[-1]
+        close(got[sl], want, tol=BF16_TOL, what="bf16 guided")
+    # the guidance term must matter at this scale (otherwise the test proves nothing)
+    un = O.sample_forward_process(sd, cfg, "energy", t_span, x_0=x0[:64], condition=cond[:64], guidance_scale=0.0)[-1]
+    gd = O.sample_forward_process(sd, cfg, "energy", t_span, x_0=x0[:64], condition=cond[:64], guidance_scale=scale)[-1]
+    assert float(np.max(np.abs(np.asarray(un) - np.asarray(gd)))) > 5 * BF16_TOL
+
+
 def test_bf16_rejects_unsupported_shapes():
     kind, cfg, m = um.build("small_vp_noise", DEV)
     m.model.compute_dtype = L.BF16
