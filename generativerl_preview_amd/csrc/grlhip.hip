@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -25,6 +26,7 @@ int device_cus() {
 }  // namespace grlhip
 
 #include "engine_f32.hip.inc"
+#include "engine_train.hip.inc"
 #include "engine_bf16_host.hip.inc"
 
 struct grlhip_plan {
@@ -65,6 +67,13 @@ NetArgs net_args(const Plan* p, const void* packed, bool grad_program, int slab_
   n.fourier_off = (int32_t)p->fourier_off;
   n.slab_base = slab_base;
   return n;
+}
+
+// GRLHIP_TRAIN_ENGINE=wave selects the per-wave fused training kernel (k_loss_f32) instead of the
+// whole-batch layer-by-layer engine (engine_train.hip.inc); for A/B measurements only.
+bool train_engine_wave() {
+  static const bool wave = [] { const char* e = std::getenv("GRLHIP_TRAIN_ENGINE"); return e && std::string(e) == "wave"; }();
+  return wave;
 }
 
 int upload(const std::vector<Op>& ops, void** d) {
@@ -293,6 +302,7 @@ int grlhip_sample_sde(const grlhip_plan* plan, const void* packed, int dtype, co
 
 size_t grlhip_loss_workspace_bytes(const grlhip_plan* plan, int64_t rows, int dtype) {
   if (!plan || !plan->p || rows <= 0 || dtype != GRLHIP_F32 || plan->p->train_fwd.empty()) return 0;
+  if (!train_engine_wave()) return train_workspace_bytes(plan->p, rows);
   return (size_t)f32_blocks(rows) * 4 * plan->p->train_slab_features * 32 * sizeof(float);
 }
 
@@ -313,6 +323,12 @@ int grlhip_loss_fwd_bwd(const grlhip_plan* plan, const void* packed, int dtype, 
   const size_t need = grlhip_loss_workspace_bytes(plan, rows, dtype);
   if (!workspace || workspace_bytes < need) return fail(GRLHIP_ERR_WORKSPACE, "workspace too small: need " + std::to_string(need));
   hipStream_t st = (hipStream_t)stream;
+  if (!train_engine_wave()) {
+    TrainCall c{t, x_t, cond, alpha, beta, target, row_weight, loss_rows, grad_flat, rows};
+    train_step(p, (const float*)packed, c, (float*)workspace, st);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   HIP_TRY(hipMemsetAsync(workspace, 0, need, st));
   LossArgs a{};
   a.net = net_args(p, packed, false, 0);
