@@ -26,7 +26,7 @@ int device_cus() {
 }  // namespace grlhip
 
 #include "engine_f32.hip.inc"
-#include "engine_train.hip.inc"
+#include "engine_batch.hip.inc"
 #include "engine_bf16_host.hip.inc"
 
 struct grlhip_plan {
@@ -69,10 +69,11 @@ NetArgs net_args(const Plan* p, const void* packed, bool grad_program, int slab_
   return n;
 }
 
-// GRLHIP_TRAIN_ENGINE=wave selects the per-wave fused training kernel (k_loss_f32) instead of the
-// whole-batch layer-by-layer engine (engine_train.hip.inc); for A/B measurements only.
-bool train_engine_wave() {
-  static const bool wave = [] { const char* e = std::getenv("GRLHIP_TRAIN_ENGINE"); return e && std::string(e) == "wave"; }();
+// GRLHIP_F32_ENGINE=wave selects the per-wave interpreter kernels (engine_f32.hip.inc: one launch per
+// call, activations in per-wave slabs) instead of the whole-batch layer-by-layer engine
+// (engine_batch.hip.inc) for every GRLHIP_F32 entry point; kept for A/B measurements.
+bool f32_engine_wave() {
+  static const bool wave = [] { const char* e = std::getenv("GRLHIP_F32_ENGINE"); return e && std::string(e) == "wave"; }();
   return wave;
 }
 
@@ -193,6 +194,7 @@ int grlhip_pack_weights(const grlhip_plan* plan, const void* const* params, int 
 size_t grlhip_workspace_bytes(const grlhip_plan* plan, const grlhip_plan* guidance, int64_t rows, int dtype) {
   if (!plan || !plan->p || rows <= 0) return 0;
   if (dtype == GRLHIP_BF16) return bf16_workspace_bytes(plan->p, guidance ? guidance->p : nullptr, rows);
+  if (!f32_engine_wave()) return batch_workspace_bytes(plan->p, guidance ? guidance->p : nullptr, rows);
   const int64_t feats = plan->p->slab_features + (guidance && guidance->p ? guidance->p->slab_features : 0);
   return (size_t)f32_blocks(rows) * 4 * feats * 32 * sizeof(float);
 }
@@ -210,6 +212,11 @@ int grlhip_net_forward(const grlhip_plan* plan, const void* packed, int dtype, c
   const size_t need = grlhip_workspace_bytes(plan, nullptr, rows, dtype);
   if (!workspace || workspace_bytes < need) return fail(GRLHIP_ERR_WORKSPACE, "workspace too small: need " + std::to_string(need));
   hipStream_t st = (hipStream_t)stream;
+  if (!f32_engine_wave()) {
+    batch_forward(p, (const float*)packed, t, x, cond, out, rows, 0, 1.0f, (float*)workspace, st);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   HIP_TRY(hipMemsetAsync(workspace, 0, need, st));
   ForwardArgs a{};
   a.net = net_args(p, packed, false, 0);
@@ -234,6 +241,11 @@ int grlhip_energy_grad(const grlhip_plan* plan, const void* packed, int dtype, c
   const size_t need = grlhip_workspace_bytes(plan, nullptr, rows, dtype);
   if (!workspace || workspace_bytes < need) return fail(GRLHIP_ERR_WORKSPACE, "workspace too small: need " + std::to_string(need));
   hipStream_t st = (hipStream_t)stream;
+  if (!f32_engine_wave()) {
+    batch_forward(p, (const float*)packed, t, x, cond, grad, rows, 1, scale, (float*)workspace, st);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   HIP_TRY(hipMemsetAsync(workspace, 0, need, st));
   ForwardArgs a{};
   a.net = net_args(p, packed, true, 0);
@@ -271,6 +283,12 @@ static int sample_common(const grlhip_plan* plan, const void* packed, int dtype,
   if (dtype != GRLHIP_F32) return fail(GRLHIP_ERR_UNSUPPORTED, "unknown dtype");
   const size_t need = grlhip_workspace_bytes(plan, guidance, rows, dtype);
   if (!workspace || workspace_bytes < need) return fail(GRLHIP_ERR_WORKSPACE, "workspace too small: need " + std::to_string(need));
+  if (!f32_engine_wave()) {
+    SampleCall c{x0, cond, coef, dW, out_final, out_traj, rows, n_steps};
+    batch_sample(p, (const float*)packed, g, (const float*)guidance_packed, c, (float*)workspace, st);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   HIP_TRY(hipMemsetAsync(workspace, 0, need, st));
   SampleArgs a{};
   a.net = net_args(p, packed, false, 0);
@@ -302,7 +320,7 @@ int grlhip_sample_sde(const grlhip_plan* plan, const void* packed, int dtype, co
 
 size_t grlhip_loss_workspace_bytes(const grlhip_plan* plan, int64_t rows, int dtype) {
   if (!plan || !plan->p || rows <= 0 || dtype != GRLHIP_F32 || plan->p->train_fwd.empty()) return 0;
-  if (!train_engine_wave()) return train_workspace_bytes(plan->p, rows);
+  if (!f32_engine_wave()) return train_workspace_bytes(plan->p, rows);
   return (size_t)f32_blocks(rows) * 4 * plan->p->train_slab_features * 32 * sizeof(float);
 }
 
@@ -323,7 +341,7 @@ int grlhip_loss_fwd_bwd(const grlhip_plan* plan, const void* packed, int dtype, 
   const size_t need = grlhip_loss_workspace_bytes(plan, rows, dtype);
   if (!workspace || workspace_bytes < need) return fail(GRLHIP_ERR_WORKSPACE, "workspace too small: need " + std::to_string(need));
   hipStream_t st = (hipStream_t)stream;
-  if (!train_engine_wave()) {
+  if (!f32_engine_wave()) {
     TrainCall c{t, x_t, cond, alpha, beta, target, row_weight, loss_rows, grad_flat, rows};
     train_step(p, (const float*)packed, c, (float*)workspace, st);
     HIP_TRY(hipGetLastError());
