@@ -332,6 +332,59 @@ def test_weighted_rows_backward_and_trainable_fourier():
             close(p.grad, grads[k], tol=3e-4, what=k)
 
 
+def test_training_batch_spanning_two_chunks_vs_oracle():
+    """The batch engine walks the rows in chunks of 65 536: per-row losses and every gradient of a batch
+    that crosses the boundary (and is not a multiple of the 128-row tile) against torch autograd on the oracle."""
+    name = "small_icfm"
+    kind, cfg, m = um.build(name, DEV)
+    B = 65536 + 333
+    gen = torch.Generator().manual_seed(5)
+    x0, x1 = torch.randn(B, 6, generator=gen), torch.rand(B, 6, generator=gen) * 2 - 1
+    cond, t, eps = torch.randn(B, 17, generator=gen), torch.rand(B, generator=gen), torch.randn(B, 6, generator=gen)
+    rows = m.flow_matching_loss(x0.to(DEV), x1.to(DEV), cond.to(DEV), average=False, t=t.to(DEV), noise=eps.to(DEV))
+    rows.mean().backward()
+    sd = gu.weights(name)
+    keys = [k for k in sd if k.startswith("model.") and not k.endswith("t_encoder.W")]
+    for k in keys:
+        sd[k].requires_grad_(True)
+    ref = O.icfm_flow_matching_loss(lambda tt, y: O.intrinsic_forward(sd, tt, y, cond), x0, x1, t, eps,
+                                    cfg["path"]["sigma"], average=False)
+    close(rows, ref.detach(), tol=2e-5, what="loss rows")
+    grads = dict(zip(keys, torch.autograd.grad(ref.mean(), [sd[k] for k in keys])))
+    n = 0
+    for k, p in m.named_parameters():
+        if k in grads:
+            close(p.grad, grads[k], tol=3e-4, what=k)
+            n += 1
+    assert n > 10
+
+
+def test_sampling_rows_spanning_two_chunks_vs_oracle():
+    """fp32 sampling walks the rows in chunks of 262 144."""
+    name = "small_vp_noise"
+    kind, cfg, m = um.build(name, DEV)
+    R = 262144 + 77
+    gen = torch.Generator().manual_seed(6)
+    x0, cond = torch.randn(R, 6, generator=gen), torch.randn(R, 17, generator=gen)
+    t_span = torch.linspace(0.0, 1.0, 4)
+    traj = m.sample_forward_process(t_span=t_span, x_0=x0.to(DEV), condition=cond.to(DEV)).cpu()
+    sd = gu.weights(name)
+    for sl in (slice(0, 200), slice(262144 - 100, 262144 + 77)):
+        want = O.sample_forward_process(sd, cfg, "diffusion", t_span, x_0=x0[sl], condition=cond[sl])
+        close(traj[:, sl], want, what="trajectory rows %s" % (sl,))
+
+
+def test_per_wave_engine_override_matches_goldens():
+    """GRLHIP_F32_ENGINE=wave (the one-launch per-wave interpreter kept for A/B runs) must stay correct: run a
+    slice of this file under it in a child process (the variable is read once per process)."""
+    import os, subprocess, sys
+    env = dict(os.environ, GRLHIP_F32_ENGINE="wave")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-p", "no:cacheprovider", "-k",
+                        "net_forward_vs_golden or losses_and_grads_vs_golden or sde_trajectories_vs_golden or energy_guidance"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_adam_step_moves_the_loss_down():
     kind, cfg, m = um.build("small_icfm", DEV)
     opt = torch.optim.Adam(m.parameters(), lr=1e-3)
