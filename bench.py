@@ -74,6 +74,21 @@ def cpu_baseline(model, rows=32768, chunk=4096):
                 action_steps_per_s=rows * N_SOLVER_STEPS / dt)
 
 
+def pmc_traffic(rows):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (separate --pmc runs of this script at
+    131072 states = 4194304 rows: scripts/profile_bench.sh), scaled linearly to this launch's rows: the counters
+    cannot be read from inside the timed run.  2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, KB -> bytes."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_bench_bf16_v3.json")
+    try:
+        with open(path) as f:
+            prof = json.load(f)
+        pm = next(v for k, v in prof.items() if k.startswith("pmc"))
+        per_row = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0 / 4194304.0
+        return per_row * rows, "profiles/r01_bench_bf16_v3.json (separate PMC passes, scaled by rows)"
+    except Exception:  # noqa: BLE001 -- the profile is optional
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,6 +148,7 @@ def main():
         kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, len(events))
         achieved = rows * N_SOLVER_STEPS * FLOP_PER_ACTION_STEP / (kernel_ms * 1e-3) / 1e12
         total_rows = rows * world * args.steps
+        traffic, traffic_src = pmc_traffic(rows)
         res = {
             "metric": "action samples/sec (100-step ODE)",
             "value": total_rows / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
@@ -144,7 +160,8 @@ def main():
                                    "obs 17 / act 6, unguided, finals only" % (args.states, N_CAND),
                        "rows_per_gpu": rows, "solver_steps": N_SOLVER_STEPS, "parallelism": "batch-sharded x%d, no collective" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                         "traffic_source": traffic_src,
                          "kernel": "k_sample_bf16", "kernel_ms": kernel_ms,
                          "algorithmic_flop_per_launch": rows * N_SOLVER_STEPS * FLOP_PER_ACTION_STEP},
         }
