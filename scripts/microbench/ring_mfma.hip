@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256, 1) void k(const char* stream, int iters, float
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   using RingT = Ring<NSLOT, CF, P, CHUNKS, CHUNKS>;
   RingT ring;
-  ring.stream = stream; ring.voff = (uint32_t)(wave * RingT::PER_WAVE + lane * 16); ring.slot0 = lds; ring.rd = lds + lane * 16; ring.wave = wave;
+  ring.init(stream, lds, wave, lane);
   ring.start();
   f32x16 acc[ACCS];
   for (int i = 0; i < ACCS; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
