@@ -1,0 +1,106 @@
+#!/usr/bin/env python
+"""Secondary benchmark, BASELINE config C3: GMPO ICFM flow-model training step -- flow_matching_loss
+forward + backward through the fp32 batch engine, ONE flat gradient all-reduce over RCCL (N > 1), Adam --
+batch 65 536 per GPU (weak scaling).  Same contract as bench.py:
+
+    python scripts/bench_train.py --gpus N --steps K --warmup W     (N > 1: torch.distributed.run)
+
+One JSON line on rank 0: training rows/s over all ranks, and the fp32-MFMA roofline of the step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+FLOP_PER_ROW = 9759936        # fwd + bwd = 3 x 2 x 1 626 656 MAC, SURVEY.md section 8d
+PEAK_F32_TFLOPS = 157.3       # MI355X dense fp32 MFMA
+BATCH = 65536
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH, help="rows per GPU")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    device = "cuda:%d" % local
+    torch.cuda.set_device(local)
+
+    import golden_lib as gl
+    import generativerl_preview_amd as G
+    from generativerl_preview_amd.distributed import allreduce_gradients
+    torch.manual_seed(0)  # identical initial weights on every rank
+    m = G.IndependentConditionalFlowModel(dict(gl.icfm_cfg(6, [512, 256, 128], 17), device=device)).to(device)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    B = args.batch
+    gen = torch.Generator(device=device).manual_seed(1 + rank)
+    x1 = torch.rand(B, 6, device=device, generator=gen) * 2 - 1
+    cond = torch.randn(B, 17, device=device, generator=gen)
+
+    def step():
+        opt.zero_grad(set_to_none=False)
+        x0 = torch.randn(B, 6, device=device, generator=gen)
+        loss = m.flow_matching_loss(x0, x1, cond)
+        loss.backward()
+        allreduce_gradients(m.parameters())
+        opt.step()
+        return loss
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert bool(torch.isfinite(loss))
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        achieved = B * FLOP_PER_ROW / (ms * 1e-3) / 1e12   # per GPU, whole step (incl. repack, all-reduce, Adam)
+        print(json.dumps({
+            "metric": "training rows/sec (ICFM flow_matching_loss fwd+bwd+all-reduce+Adam)",
+            "value": B * world * args.steps / elapsed, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C3 GMPO ICFM training step, batch %d per GPU, net [512,256,128], obs 17 / act 6, sigma 0.1" % B,
+                       "parallelism": "data parallel x%d, one flat fp32 all-reduce per step" % world},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_TFLOPS, "traffic": None,
+                         "note": "whole step per GPU over wall time; per-kernel split: scripts/profile_train.sh"},
+            "final_loss": float(loss)}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
