@@ -158,7 +158,8 @@ int64_t grlhip_grad_offset(const grlhip_plan* plan, int index) {
 size_t grlhip_packed_bytes(const grlhip_plan* plan, int dtype) {
   if (!plan || !plan->p) return 0;
   if (dtype == GRLHIP_F32) return (size_t)plan->p->packed_floats * sizeof(float);
-  if (dtype == GRLHIP_BF16) return bf16_packed_bytes(plan->p);
+  // bf16 on a shape without a fused kernel runs the batch engine with bf16 MFMAs on the fp32 image
+  if (dtype == GRLHIP_BF16) return bf16_fused_ok(plan->p) ? bf16_packed_bytes(plan->p) : (size_t)plan->p->packed_floats * sizeof(float);
   return 0;
 }
 
@@ -170,8 +171,8 @@ int grlhip_pack_weights(const grlhip_plan* plan, const void* const* params, int 
   for (int i = 0; i < n; ++i)
     if (!params[i]) return fail(GRLHIP_ERR_INVALID, "null parameter pointer: " + p->params[i].name);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == GRLHIP_BF16) return bf16_pack(p, params, packed, st, g_err);
-  if (dtype != GRLHIP_F32) return fail(GRLHIP_ERR_UNSUPPORTED, "unknown dtype");
+  if (dtype == GRLHIP_BF16 && bf16_fused_ok(p)) return bf16_pack(p, params, packed, st, g_err);
+  if (dtype != GRLHIP_F32 && dtype != GRLHIP_BF16) return fail(GRLHIP_ERR_UNSUPPORTED, "unknown dtype");
   float* dst = (float*)packed;
   for (const LinearDesc& l : p->linears) {
     PackArgs a{};
@@ -193,7 +194,10 @@ int grlhip_pack_weights(const grlhip_plan* plan, const void* const* params, int 
 
 size_t grlhip_workspace_bytes(const grlhip_plan* plan, const grlhip_plan* guidance, int64_t rows, int dtype) {
   if (!plan || !plan->p || rows <= 0) return 0;
-  if (dtype == GRLHIP_BF16) return bf16_workspace_bytes(plan->p, guidance ? guidance->p : nullptr, rows);
+  if (dtype == GRLHIP_BF16) {
+    if (bf16_fused_ok(plan->p)) return bf16_workspace_bytes(plan->p, guidance ? guidance->p : nullptr, rows);
+    return batch_workspace_bytes(plan->p, guidance ? guidance->p : nullptr, rows);
+  }
   if (!f32_engine_wave()) return batch_workspace_bytes(plan->p, guidance ? guidance->p : nullptr, rows);
   const int64_t feats = plan->p->slab_features + (guidance && guidance->p ? guidance->p->slab_features : 0);
   return (size_t)f32_blocks(rows) * 4 * feats * 32 * sizeof(float);
@@ -277,9 +281,20 @@ static int sample_common(const grlhip_plan* plan, const void* packed, int dtype,
       return fail(GRLHIP_ERR_INVALID, "guidance plan must be a CONCAT_MLP over the same x/cond dims");
   }
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == GRLHIP_BF16)
-    return bf16_sample(p, packed, g, guidance_packed, x0, cond, coef, dW, n_steps, rows, out_final, out_traj,
-                       workspace, workspace_bytes, st, g_err);
+  if (dtype == GRLHIP_BF16) {
+    const bool nf = bf16_fused_ok(p), gf = g && bf16_fused_ok(g);
+    if (nf)  // the persistent fused integrator (rejects pairs it has no kernel for)
+      return bf16_sample(p, packed, g, guidance_packed, x0, cond, coef, dW, n_steps, rows, out_final, out_traj,
+                         workspace, workspace_bytes, st, g_err);
+    if (gf) return fail(GRLHIP_ERR_UNSUPPORTED, "bf16: this energy net only has a fused kernel but the sampler net has none; use GRLHIP_F32");
+    // any other shape: the batch engine with bf16 MFMAs (both images are in the fp32 layout)
+    const size_t need = grlhip_workspace_bytes(plan, guidance, rows, dtype);
+    if (!workspace || workspace_bytes < need) return fail(GRLHIP_ERR_WORKSPACE, "workspace too small: need " + std::to_string(need));
+    SampleCall c{x0, cond, coef, dW, out_final, out_traj, rows, n_steps};
+    batch_sample(p, (const float*)packed, g, (const float*)guidance_packed, c, (float*)workspace, st, true);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   if (dtype != GRLHIP_F32) return fail(GRLHIP_ERR_UNSUPPORTED, "unknown dtype");
   const size_t need = grlhip_workspace_bytes(plan, guidance, rows, dtype);
   if (!workspace || workspace_bytes < need) return fail(GRLHIP_ERR_WORKSPACE, "workspace too small: need " + std::to_string(need));

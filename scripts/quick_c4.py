@@ -31,3 +31,11 @@ t = timed(lambda: q.sample(t_span=ts, x_0=x0, condition=cond, guidance_scale=1.0
                            solver_config=dict(type="SDESolver", args=dict(dt=0.01))))
 print(json.dumps(dict(config="C4 QGPO guided Euler-Maruyama %d steps, %d rows" % (n_inner, R), engine="bf16", seconds=t,
                       action_steps_per_s=R * n_inner / t, tflops=R * n_inner * 3547712 / t / 1e12)), flush=True)
+
+# C5 on the batch engine with bf16 MFMAs (no fused kernel for the [1024] net)
+g5 = G.DiffusionModel(dict(gl.diffusion_cfg(64, gl.GVP, "velocity_function", [1024]), device=DEV)).to(DEV)
+g5.model.compute_dtype = L.BF16
+R5 = 262144
+t = timed(lambda: g5.sample(t_span=ts, batch_size=R5), 1)
+print(json.dumps(dict(config="C5 GVP [1024] D=64, 100-step ODE, batch 262144", engine="bf16 (batch engine)", seconds=t,
+                      action_steps_per_s=R5 * 100 / t, tflops=R5 * 100 * 6950912 / t / 1e12)), flush=True)

@@ -254,11 +254,37 @@ def test_bf16_guided_ode_vs_oracle(rows, steps, scale):
     assert float(np.max(np.abs(np.asarray(un) - np.asarray(gd)))) > 5 * BF16_TOL
 
 
-def test_bf16_rejects_unsupported_shapes():
-    kind, cfg, m = um.build("small_vp_noise", DEV)
+@pytest.mark.parametrize("name,rows,steps", [("small_vp_noise", 333, 20), ("gvp_wide", 300, 20), ("small_uncond_noise", 130, 50),
+                                             ("small_icfm", 257, 20)])
+def test_bf16_generic_shapes_run_on_the_batch_engine(name, rows, steps):
+    """Shapes without a fused bf16 kernel (C5's [1024] net, the small nets): GRLHIP_BF16 runs the batch engine
+    with bf16 MFMAs (fp32 activations in HBM, bf16 operands, fp32 accumulate) -- same 2e-2 tolerance."""
+    kind, cfg, m, sd = _bf16_model(name)
+    S = gu.cond_dim(cfg)
+    D = cfg["x_size"]
+    gen = torch.Generator().manual_seed(17)
+    x0 = torch.randn(rows, D, generator=gen)
+    cond = torch.randn(rows, S, generator=gen) if S else None
+    t_span = torch.linspace(0.0, 1.0, steps + 1)
+    kw = dict(t_span=t_span, x_0=x0.to(DEV))
+    if S:
+        kw["condition"] = cond.to(DEV)
+    got = m.sample(**kw).cpu()
+    want = O.sample_forward_process(sd, cfg, kind, t_span, x_0=x0, condition=cond)[-1]
+    close(got, want, tol=BF16_TOL, what="bf16 batch engine %s" % name)
+    m.model.compute_dtype = L.F32
+    exact = m.sample(**kw).cpu()
+    assert float((got - exact).abs().max()) > 0.0, "bf16 path returned the fp32 result bit for bit: not the bf16 kernels"
+
+
+def test_bf16_mixed_pair_is_rejected():
+    """small net (batch engine, fp32-layout image) + the [256,256] energy net (fused-kernel fragment image): no
+    bf16 kernel takes that pair; the library must say so instead of reading an image in the wrong layout."""
+    kind, cfg, m = um.build("small_energy", DEV)
     m.model.compute_dtype = L.BF16
     with pytest.raises(L.GrlHipError, match="bf16"):
-        m.sample(t_span=torch.linspace(0, 1, 5), x_0=torch.zeros(4, 6, device=DEV), condition=torch.zeros(4, 17, device=DEV))
+        m.sample(t_span=torch.linspace(0, 1, 5), x_0=torch.zeros(4, 6, device=DEV), condition=torch.zeros(4, 17, device=DEV),
+                 guidance_scale=1.0)
 
 
 # ----------------------------------------------------------------------------- fused training step
