@@ -39,7 +39,9 @@ typedef enum {
 
 typedef enum {
   GRLHIP_F32 = 0, /* fp32 storage, fp32-input MFMA (exact fp32 fma chains) */
-  GRLHIP_BF16 = 1 /* bf16 weights/activations, fp32 accumulate, fp32 state and schedule math */
+  GRLHIP_BF16 = 1 /* sampling only: bf16 MFMA operands, fp32 accumulate, fp32 state and schedule math.
+                     [512,256,128] nets (+ the [256,256] energy net) run the persistent fused integrator,
+                     every other shape the layer-by-layer batch engine with bf16 MFMAs. */
 } grlhip_dtype;
 
 /* Network description = the constructor arguments of the reference module.
@@ -78,14 +80,17 @@ int grlhip_plan_num_params(const grlhip_plan* plan);
 int grlhip_plan_param_info(const grlhip_plan* plan, int index, char* name_buf, size_t name_buf_len,
                            int32_t* rows, int32_t* cols);
 
-/* Bytes of the packed weight image for `dtype`. */
+/* Bytes of the packed weight image for `dtype` (the image layout is private to the library and differs
+ * per dtype and shape: always produce it with grlhip_pack_weights for the same plan and dtype). */
 size_t grlhip_packed_bytes(const grlhip_plan* plan, int dtype);
 /* Derive the packed (padded / transposed / fragment-ordered) weight image from the reference-layout
  * parameters.  `params` is a HOST array of n DEVICE pointers (fp32), in grlhip_plan_param_info order. */
 int grlhip_pack_weights(const grlhip_plan* plan, const void* const* params, int n, int dtype,
                         void* packed, void* stream);
 
-/* Workspace bytes for a call over `rows` rows (sampling / forward); `guidance` may be NULL. */
+/* Workspace bytes for a call over `rows` rows (sampling / forward); `guidance` may be NULL.  fp32 calls
+ * stream activations through the workspace (a feature-major slab of up to 262 144 rows: gigabytes for the
+ * QGPO net); the fused bf16 integrator needs < 5 MB. */
 size_t grlhip_workspace_bytes(const grlhip_plan* plan, const grlhip_plan* guidance, int64_t rows, int dtype);
 
 /* Replaces: IntrinsicModel.forward, grl/generative_models/intrinsic_model.py:54-75 --
@@ -124,7 +129,8 @@ int grlhip_energy_grad(const grlhip_plan* plan, const void* packed, int dtype, c
  * (grl/numerical_methods/numerical_solvers/ode_solver.py:51-79,168-185) driven from
  * DiffusionModel.sample_forward_process (diffusion_model/diffusion_model.py:282-304) /
  * EnergyConditionalDiffusionModel (:406-435) / IndependentConditionalFlowModel (:285-319):
- * all n_steps Euler steps of all rows in ONE launch.  guidance/guidance_packed may be NULL.
+ * all n_steps Euler steps of all rows enqueued by ONE call (one launch on the fused bf16 path, one launch
+ * per layer and step on the batch engine; never a host synchronisation).  guidance/guidance_packed may be NULL.
  * out_final[R,D] always written; out_traj[n_emit+1, R, D] optional (slot 0 = x0). */
 int grlhip_sample_ode(const grlhip_plan* plan, const void* packed, int dtype,
                       const grlhip_plan* guidance, const void* guidance_packed,
