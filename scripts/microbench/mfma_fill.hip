@@ -14,7 +14,9 @@ __global__ __launch_bounds__(256, 1) void k(int iters, float* out, unsigned long
   f32x16 other = {0};   // unrelated accumulator (AGPR): source of v_accvgpr_read fillers
   bf16x8 a, b;
   for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(0.01f * (lane + e)); b[e] = (__bf16)(0.02f * (lane - e)); }
-  float x0 = lane * 0.1f, x1 = 1.0f, x2 = 2.0f, x3 = 3.0f;
+  float x0 = lane * 0.1f, x1 = 1.0f, x2 = 2.0f, x3 = 3.0f, y0 = 0.f, y1 = 0.f;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 z0 = {0.f, 0.f}, z1 = {1.f, 2.f};
   asm volatile("" : "+a"(other));
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #pragma clang loop unroll(disable)
@@ -31,12 +33,24 @@ __global__ __launch_bounds__(256, 1) void k(int iters, float* out, unsigned long
         asm volatile("v_accvgpr_read_b32 %0, %4\n v_accvgpr_read_b32 %1, %4\n v_fma_f32 %2, %2, %3, %0\n v_fma_f32 %3, %3, %0, %1" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "a"(other[m & 15]));
       if (MODE == 4)  // 2 accvgpr writes + 2 VALU
         asm volatile("v_accvgpr_write_b32 %4, %0\n v_fma_f32 %2, %2, %3, %0\n v_fma_f32 %3, %3, %0, %1\n v_fma_f32 %1, %1, %0, %2" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+a"(other[m & 15]));
+      if (MODE >= 10) {  // a full gap: 4 fma + two more instructions of the kind under test (independent)
+        asm volatile("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %1, %1, %2, %3\n v_fma_f32 %2, %2, %3, %0\n v_fma_f32 %3, %3, %0, %1" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+        if (MODE == 10) asm volatile("v_fma_f32 %0, %2, %2, %2\n v_fma_f32 %1, %3, %3, %3" : "=v"(y0), "=v"(y1) : "v"(x2), "v"(x3));
+        if (MODE == 11) asm volatile("v_exp_f32 %0, %2\n v_exp_f32 %1, %3" : "=v"(y0), "=v"(y1) : "v"(x2), "v"(x3));
+        if (MODE == 12) asm volatile("v_rcp_f32 %0, %2\n v_rcp_f32 %1, %3" : "=v"(y0), "=v"(y1) : "v"(x2), "v"(x3));
+        if (MODE == 13) asm volatile("v_exp_f16 %0, %2\n v_exp_f16 %1, %3" : "=v"(y0), "=v"(y1) : "v"(x2), "v"(x3));
+        if (MODE == 14) asm volatile("v_rcp_f16 %0, %2\n v_rcp_f16 %1, %3" : "=v"(y0), "=v"(y1) : "v"(x2), "v"(x3));
+        if (MODE == 15) asm volatile("v_exp_f32 %0, %2\n v_rcp_f32 %1, %3" : "=v"(y0), "=v"(y1) : "v"(x2), "v"(x3));
+        if (MODE == 16) asm volatile("v_exp_f32 %0, %1" : "=v"(y0) : "v"(x2));
+        if (MODE == 17) asm volatile("v_pk_mul_f32 %0, %1, %1" : "=v"(z0) : "v"(z1));
+        if (MODE == 18) asm volatile("v_rcp_iflag_f32 %0, %2\n v_rsq_f32 %1, %3" : "=v"(y0), "=v"(y1) : "v"(x2), "v"(x3));
+      }
       if (MODE == 6)  // cvt_pk + 3 VALU
         asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2\n v_fma_f32 %1, %1, %2, %3\n v_fma_f32 %2, %2, %3, %1\n v_fma_f32 %3, %3, %1, %2" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
     }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-  float s = x0 + x1 + x2 + x3;
+  float s = x0 + x1 + x2 + x3 + y0 + y1 + z0[0] + z0[1];
   for (int r = 0; r < 16; ++r) s += acc[r] + other[r];
   out[blockIdx.x * 256 + threadIdx.x] = s;
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
@@ -65,5 +79,14 @@ int main() {
   run<3>(out, dc, "2 accvgpr_read (other acc) + 2 fma");
   run<4>(out, dc, "1 accvgpr_write (other acc) + 3 fma");
   run<6>(out, dc, "cvt_pk + 3 fma");
+  run<10>(out, dc, "4 fma + 2 fma");
+  run<11>(out, dc, "4 fma + 2 v_exp_f32");
+  run<12>(out, dc, "4 fma + 2 v_rcp_f32");
+  run<13>(out, dc, "4 fma + 2 v_exp_f16");
+  run<14>(out, dc, "4 fma + 2 v_rcp_f16");
+  run<15>(out, dc, "4 fma + v_exp_f32 + v_rcp_f32");
+  run<16>(out, dc, "4 fma + 1 v_exp_f32");
+  run<17>(out, dc, "4 fma + 1 v_pk_mul_f32");
+  run<18>(out, dc, "4 fma + v_rcp_iflag_f32 + v_rsq_f32");
   return 0;
 }
