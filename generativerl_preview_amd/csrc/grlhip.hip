@@ -149,6 +149,18 @@ int grlhip_plan_param_info(const grlhip_plan* plan, int index, char* name_buf, s
   return 0;
 }
 
+int grlhip_plan_program_info(const grlhip_plan* plan, int program, int32_t* n_ops, int32_t* n_launches) {
+  if (!plan || !plan->p || program < 0 || program > 3) return fail(GRLHIP_ERR_INVALID, "program must be 0..3");
+  const Plan* p = plan->p;
+  const std::vector<Op>& prog = program == 0 ? p->fwd : program == 1 ? p->grad : program == 2 ? p->train_fwd : p->train_bwd;
+  int launches = 0;
+  for (size_t i = 0; i < prog.size(); ++i, ++launches)
+    if (batch_fusable(p, prog, i)) ++i;
+  if (n_ops) *n_ops = (int32_t)prog.size();
+  if (n_launches) *n_launches = launches;
+  return 0;
+}
+
 int64_t grlhip_grad_numel(const grlhip_plan* plan) { return plan && plan->p ? plan->p->grad_numel : 0; }
 int64_t grlhip_grad_offset(const grlhip_plan* plan, int index) {
   if (!plan || !plan->p || index < 0 || index >= (int)plan->p->params.size()) return -1;

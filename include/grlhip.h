@@ -80,6 +80,12 @@ int grlhip_plan_num_params(const grlhip_plan* plan);
 int grlhip_plan_param_info(const grlhip_plan* plan, int index, char* name_buf, size_t name_buf_len,
                            int32_t* rows, int32_t* cols);
 
+/* Introspection (no counterpart in the reference; used by the tests and to size stream captures): the number of
+ * ops of one of the plan's programs (0 forward, 1 energy forward + input gradient, 2 training forward,
+ * 3 training backward) and the number of kernel launches the batch engine turns it into per pass (a plain
+ * linear whose only consumer is the residual input of the next linear is fused into that GEMM). */
+int grlhip_plan_program_info(const grlhip_plan* plan, int program, int32_t* n_ops, int32_t* n_launches);
+
 /* Bytes of the packed weight image for `dtype` (the image layout is private to the library and differs
  * per dtype and shape: always produce it with grlhip_pack_weights for the same plan and dtype). */
 size_t grlhip_packed_bytes(const grlhip_plan* plan, int dtype);

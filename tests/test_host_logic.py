@@ -41,6 +41,24 @@ def test_state_dict_matches_reference_keys(name):
     assert sorted(names) == sorted(k for k, _ in m.model.model.named_parameters())
 
 
+@pytest.mark.parametrize("name,blocks_with_modify,blocks", [("qgpo_noise", 3, 6), ("gvp_wide", 1, 2), ("swiss_noise", 3, 6)])
+def test_batch_engine_fuses_time_mlp_and_modify_x(name, blocks_with_modify, blocks):
+    """The peephole of the batch engine: every residual block's time-MLP, and modify_x where the block changes
+    width, become the second accumulator of the consuming GEMM; nothing in the backward program may fuse."""
+    kind, cfg, m = um.build(name)
+    h = m.model.plan.handle
+    info = {}
+    for prog in range(4):
+        n_ops, n_launch = ctypes.c_int32(), ctypes.c_int32()
+        L.check(L.lib().grlhip_plan_program_info(h, prog, ctypes.byref(n_ops), ctypes.byref(n_launch)))
+        info[prog] = (n_ops.value, n_launch.value)
+    fused = blocks + blocks_with_modify
+    assert info[0][0] - info[0][1] == fused, info
+    assert info[2][0] - info[2][1] == fused, info
+    assert info[3][0] == info[3][1] and info[3][0] > 0, info
+    assert info[1] == (0, 0)
+
+
 def test_plan_rejects_bad_wiring():
     from generativerl_preview_amd.engine import NetPlan
     with pytest.raises(L.GrlHipError, match="hidden"):
