@@ -13,6 +13,7 @@ from ...numerical_methods.numerical_solvers.sde_solver import SDESolver
 from ...numerical_methods.probability_path import GaussianConditionalProbabilityPath
 from ..diffusion_process import DiffusionProcess
 from ..intrinsic_model import IntrinsicModel
+from ..model_functions import heads
 from ..model_functions.losses import fused_loss, prepare_flow_matching, prepare_score_matching
 from ..random_generator import gaussian_random_variable
 from ..sampling import expand_inputs, reshape_output
@@ -42,6 +43,19 @@ class DiffusionModel(nn.Module):
 
     def get_type(self):
         return "DiffusionModel"
+
+    # ------------------------------------------------------------------ heads (diffusion_model.py:985-1123)
+    def score_function(self, t, x, condition=None):
+        return heads.score(self.model_type, self.path, self.model(t, x, condition), t, x)
+
+    def noise_function(self, t, x, condition=None):
+        return heads.noise(self.model_type, self.path, self.model(t, x, condition), t, x)
+
+    def velocity_function(self, t, x, condition=None):
+        return heads.velocity(self.model_type, self.path, self.model(t, x, condition), t, x)
+
+    def data_prediction_function(self, t, x, condition=None):
+        return heads.data_prediction(self.model_type, self.path, self.model(t, x, condition), t, x)
 
     # ------------------------------------------------------------------ sampling
     def sample(self, t_span: torch.Tensor = None, batch_size: Union[torch.Size, int, Tuple[int], List[int]] = None,

@@ -41,6 +41,25 @@ def test_net_forward_vs_golden(name):
     close(out, g["net"], what="net")
 
 
+@pytest.mark.parametrize("name", [n for n in ALL if not n.endswith("icfm") and n != "icfm_cond"])
+def test_head_conversions_vs_golden(name):
+    """DiffusionModel.score_function / noise_function / velocity_function / data_prediction_function (HIP forward +
+    the schedule algebra as written in the reference); a head the reference itself cannot produce must raise."""
+    kind, cfg, m = um.build(name, DEV)
+    g = gu.load("model_%s.npz" % name)
+    t, x, c = cu(g["t"]), cu(g["x"]), cu(g.get("cond"))
+    n = 0
+    for h, fn in (("score", m.score_function), ("noise", m.noise_function), ("velocity", m.velocity_function),
+                  ("data", m.data_prediction_function)):
+        if "head_" + h in g:
+            close(fn(t, x, c), g["head_" + h], tol=2e-4, what="head_" + h)
+            n += 1
+        else:
+            with pytest.raises(NotImplementedError):
+                fn(t, x, c)
+    assert n >= 3
+
+
 @pytest.mark.parametrize("name", ["qgpo_noise", "small_energy"])
 def test_energy_guidance_vs_golden(name):
     kind, cfg, m = um.build(name, DEV)
