@@ -8,6 +8,7 @@ import torch.nn as nn
 
 from ...config import as_config
 from ...numerical_methods.numerical_solvers import get_solver
+from ...numerical_methods.numerical_solvers.dpm_solver import DPMSolver
 from ...numerical_methods.numerical_solvers.ode_solver import ODESolver
 from ...numerical_methods.numerical_solvers.sde_solver import SDESolver
 from ...numerical_methods.probability_path import GaussianConditionalProbabilityPath
@@ -68,6 +69,9 @@ class DiffusionModel(nn.Module):
     def _function(self, guidance_scale):
         return self.model, self.model_type
 
+    def _dpm_functions(self, guidance_scale):
+        return self.noise_function, self.data_prediction_function
+
     def sample_forward_process(self, t_span: torch.Tensor = None, batch_size=None, x_0=None, condition=None,
                                with_grad: bool = False, solver_config=None, noise_increments=None,
                                _final_only=False, _guidance_scale=None):
@@ -85,7 +89,15 @@ class DiffusionModel(nn.Module):
             assert hasattr(self, "solver"), "solver must be specified in config or solver_config"
             solver = self.solver
         function, function_type = self._function(_guidance_scale)
-        if isinstance(solver, ODESolver):
+        if isinstance(solver, DPMSolver):
+            # diffusion_model.py:255-279 / energy_conditional_diffusion_model.py:370-405
+            assert t_span is None, "DPMSolver does not support t_span argument assignment"
+            noise_fn, data_fn = self._dpm_functions(_guidance_scale)
+            data = solver.integrate(diffusion_process=self.diffusion_process, noise_function=noise_fn,
+                                    data_prediction_function=data_fn, x=x, condition=condition, save_intermediate=True)
+            if _final_only:
+                data = data[-1]
+        elif isinstance(solver, ODESolver):
             drift = self.diffusion_process.reverse_ode(function=function, function_type=function_type,
                                                        condition=condition).drift
             data = solver.integrate(drift=drift, x0=x, t_span=t_span, return_trajectory=not _final_only)

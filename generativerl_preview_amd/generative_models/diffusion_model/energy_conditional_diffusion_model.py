@@ -50,6 +50,21 @@ class EnergyConditionalDiffusionModel(DiffusionModel):
         gs = 1.0 if guidance_scale is None else guidance_scale
         return GuidedScore(self.model, self.model_type, self.energy_guidance.model, gs), "score_function"
 
+    def _dpm_functions(self, guidance_scale):
+        gs = 1.0 if guidance_scale is None else guidance_scale
+        return (lambda t, x, c: self.noise_function_with_energy_guidance(t, x, c, gs),
+                lambda t, x, c: self.data_prediction_function_with_energy_guidance(t, x, c, gs))
+
+    def noise_function_with_energy_guidance(self, t, x, condition=None, guidance_scale: float = 1.0):
+        """:1235-1260"""
+        return -self.score_function_with_energy_guidance(t, x, condition, guidance_scale) * self.diffusion_process.std(t, x)
+
+    def data_prediction_function_with_energy_guidance(self, t, x, condition=None, guidance_scale: float = 1.0):
+        """:1281-1306 (as written: -std * x)"""
+        dp = self.diffusion_process
+        return (-dp.std(t, x) * x + dp.covariance(t, x)
+                * self.score_function_with_energy_guidance(t, x, condition, guidance_scale)) / dp.scale(t, x)
+
     def sample(self, t_span=None, batch_size=None, x_0=None, condition=None, guidance_scale: float = 1.0,
                with_grad: bool = False, solver_config=None, **kw):
         """:168-213"""

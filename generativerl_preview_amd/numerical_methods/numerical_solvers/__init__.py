@@ -1,4 +1,5 @@
 """Solver registry (grl/numerical_methods/numerical_solvers/__init__.py:6-18)."""
+from .dpm_solver import DPMSolver
 from .ode_solver import ODESolver
 from .sde_solver import SDESolver
 
@@ -10,6 +11,7 @@ def get_solver(solver_type):
 
 
 SOLVERS = {
+    "DPMSolver".lower(): DPMSolver,
     "ODESolver".lower(): ODESolver,
     "SDESolver".lower(): SDESolver,
 }

@@ -137,6 +137,21 @@ class Path:
         s = torch.sin(0.5 * torch.pi * t)
         return s * s
 
+    def log_scale(self, t):  # probability_path.py:265-293
+        if self.type == "linear_vp_sde":
+            return -0.25 * t ** 2 * (self.b1 - self.b0) - 0.5 * t * self.b0
+        return torch.log(torch.cos(0.5 * torch.pi * t))
+
+    def half_log_snr(self, t):  # probability_path.py:479-498 (linear_vp_sde only, like the reference)
+        assert self.type == "linear_vp_sde"
+        return self.log_scale(t) - 0.5 * torch.log(1.0 - self.scale(t) ** 2)
+
+    def inverse_half_log_snr(self, lam):  # probability_path.py:500-538
+        assert self.type == "linear_vp_sde"
+        num = 2.0 * torch.logaddexp(-2.0 * lam, torch.zeros((1,)).to(lam))
+        den = torch.sqrt(self.b0 ** 2 + (self.b1 - self.b0) * num) + self.b0
+        return num / den
+
 
 def _b(v, x):
     """DiffusionProcess broadcast: (B,) -> x.shape, diffusion_process.py:55-57."""
@@ -407,3 +422,137 @@ def icfm_flow_matching_loss(net_fn, x0, x1, t, eps, sigma, average=True):
     tb = _b(t, x0)
     x_t = x0 * (1.0 - tb) + x1 * tb + sigma * eps
     return _row_loss(net_fn(t, x_t), x1 - x0, average)
+
+
+# ----------------------------------------------------------------------------- DPM-Solver
+def dpm_orders_singlestep(steps, order):
+    """get_orders_for_singlestep_solver, numerical_solvers/dpm_solver.py:163-230."""
+    if order == 3:
+        K = steps // 3 + 1
+        if steps % 3 == 0:
+            return [3] * (K - 2) + [2, 1]
+        if steps % 3 == 1:
+            return [3] * (K - 1) + [1]
+        return [3] * (K - 1) + [2]
+    if order == 2:
+        if steps % 2 == 0:
+            K = steps // 2 + 1
+            return [2] * (K - 2) + [1] * 2
+        return [2] * (steps // 2) + [1]
+    if order == 1:
+        return [1] * steps
+    raise ValueError(order)
+
+
+def dpm_time_steps(path, t_T, t_0, N, skip_type="time_uniform"):
+    """get_time_steps, dpm_solver.py:127-161."""
+    if skip_type == "logSNR":
+        lT, l0 = path.half_log_snr(torch.tensor(t_T)), path.half_log_snr(torch.tensor(t_0))
+        return path.inverse_half_log_snr(torch.linspace(float(lT), float(l0), N + 1))
+    if skip_type == "time_uniform":
+        return torch.linspace(t_T, t_0, N + 1)
+    if skip_type == "time_quadratic":
+        return torch.linspace(t_T ** 0.5, t_0 ** 0.5, N + 1).pow(2)
+    raise ValueError(skip_type)
+
+
+def dpm_solver_integrate(path, noise_fn, data_fn, x, steps=20, order=2, type="dpm_solver", method="singlestep",
+                         solver_type="dpm_solver", skip_type="time_uniform", denoise=False):
+    """DPMSolver.integrate with method 'singlestep' / 'singlestep_fixed' (dpm_solver.py:83-905: first update
+    :250-299, second :301-391, third :393-523, driver :854-904).  ``noise_fn(t, x)`` / ``data_fn(t, x)`` take
+    t of shape (B,).  Returns the stacked states (len(orders) + 1, B, ...) like ``save_intermediate=True``."""
+    plus = type == "dpm_solver++"
+    high = solver_type == "dpm_solver"
+    B = x.shape[0]
+    model_fn = (lambda xx, tt: data_fn(tt.expand(B), xx)) if plus else (lambda xx, tt: noise_fn(tt.expand(B), xx))
+    lam, la, sig = path.half_log_snr, path.log_scale, path.std
+
+    def first(x, s, t):
+        h = lam(t) - lam(s)
+        m = model_fn(x, s)
+        if plus:
+            return sig(t) / sig(s) * x - torch.exp(la(t)) * torch.expm1(-h) * m
+        return torch.exp(la(t) - la(s)) * x - sig(t) * torch.expm1(h) * m
+
+    def second(x, s, t, r1):
+        r1 = 0.5 if r1 is None else r1
+        h = lam(t) - lam(s)
+        s1 = path.inverse_half_log_snr(lam(s) + r1 * h)[0]
+        m = model_fn(x, s)
+        if plus:
+            p11, p1 = torch.expm1(-r1 * h), torch.expm1(-h)
+            x1 = sig(s1) / sig(s) * x - torch.exp(la(s1)) * p11 * m
+            m1 = model_fn(x1, s1)
+            at = torch.exp(la(t))
+            if high:
+                return sig(t) / sig(s) * x - at * p1 * m - (0.5 / r1) * at * p1 * (m1 - m)
+            return sig(t) / sig(s) * x - at * p1 * m + (1.0 / r1) * at * ((torch.exp(-h) - 1.0) / h + 1.0) * (m1 - m)
+        p11, p1 = torch.expm1(r1 * h), torch.expm1(h)
+        x1 = torch.exp(la(s1) - la(s)) * x - sig(s1) * p11 * m
+        m1 = model_fn(x1, s1)
+        e = torch.exp(la(t) - la(s))
+        if high:
+            return e * x - sig(t) * p1 * m - (0.5 / r1) * sig(t) * p1 * (m1 - m)
+        return e * x - sig(t) * p1 * m - (1.0 / r1) * sig(t) * ((torch.exp(h) - 1.0) / h - 1.0) * (m1 - m)
+
+    def third(x, s, t, r1, r2):
+        r1 = 1.0 / 3.0 if r1 is None else r1
+        r2 = 2.0 / 3.0 if r2 is None else r2
+        h = lam(t) - lam(s)
+        s1 = path.inverse_half_log_snr(lam(s) + r1 * h)[0]
+        s2 = path.inverse_half_log_snr(lam(s) + r2 * h)[0]
+        m = model_fn(x, s)
+        if plus:
+            p11, p12, p1 = torch.expm1(-r1 * h), torch.expm1(-r2 * h), torch.expm1(-h)
+            p22 = torch.expm1(-r2 * h) / (r2 * h) + 1.0
+            p2 = p1 / h + 1.0
+            p3 = p2 / h - 0.5
+            x1 = sig(s1) / sig(s) * x - torch.exp(la(s1)) * p11 * m
+            m1 = model_fn(x1, s1)
+            a2, at = torch.exp(la(s2)), torch.exp(la(t))
+            x2 = sig(s2) / sig(s) * x - a2 * p12 * m + r2 / r1 * a2 * p22 * (m1 - m)
+            m2 = model_fn(x2, s2)
+            if high:
+                return sig(t) / sig(s) * x - at * p1 * m + (1.0 / r2) * at * p2 * (m2 - m)
+            D10, D11 = (1.0 / r1) * (m1 - m), (1.0 / r2) * (m2 - m)
+            D1, D2 = (r2 * D10 - r1 * D11) / (r2 - r1), 2.0 * (D11 - D10) / (r2 - r1)
+            return sig(t) / sig(s) * x - at * p1 * m + at * p2 * D1 - at * p3 * D2
+        p11, p12, p1 = torch.expm1(r1 * h), torch.expm1(r2 * h), torch.expm1(h)
+        p22 = torch.expm1(r2 * h) / (r2 * h) - 1.0
+        p2 = p1 / h - 1.0
+        p3 = p2 / h - 0.5
+        x1 = torch.exp(la(s1) - la(s)) * x - sig(s1) * p11 * m
+        m1 = model_fn(x1, s1)
+        x2 = torch.exp(la(s2) - la(s)) * x - sig(s2) * p12 * m - r2 / r1 * sig(s2) * p22 * (m1 - m)
+        m2 = model_fn(x2, s2)
+        e = torch.exp(la(t) - la(s))
+        if high:
+            return e * x - sig(t) * p1 * m - (1.0 / r2) * sig(t) * p2 * (m2 - m)
+        D10, D11 = (1.0 / r1) * (m1 - m), (1.0 / r2) * (m2 - m)
+        D1, D2 = (r2 * D10 - r1 * D11) / (r2 - r1), 2.0 * (D11 - D10) / (r2 - r1)
+        return e * x - sig(t) * p1 * m - sig(t) * p2 * D1 - sig(t) * p3 * D2
+
+    t_0, t_T = 0.00001, path.t_max
+    if method == "singlestep":
+        orders = dpm_orders_singlestep(steps, order)
+        ts = dpm_time_steps(path, t_T, t_0, steps, skip_type)
+    elif method == "singlestep_fixed":
+        K = steps // order
+        orders = [order] * K
+        ts = dpm_time_steps(path, t_T, t_0, K * order, skip_type)
+    else:
+        raise NotImplementedError(method)
+    xs = [x.clone()]
+    i = 0
+    for o in orders:
+        s, t = ts[i], ts[i + o]
+        h = lam(ts[i + o]) - lam(ts[i])
+        r1 = None if o <= 1 else (lam(ts[i + 1]) - lam(ts[i])) / h
+        r2 = None if o <= 2 else (lam(ts[i + 2]) - lam(ts[i])) / h
+        x = first(x, s, t) if o == 1 else second(x, s, t, r1) if o == 2 else third(x, s, t, r1, r2)
+        xs.append(x.clone())
+        i += o
+    if denoise:
+        x = data_fn(torch.ones(B) * t_0, x)
+        xs[-1] = x.clone()
+    return torch.stack(xs, 0)

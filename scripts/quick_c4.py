@@ -39,3 +39,12 @@ R5 = 262144
 t = timed(lambda: g5.sample(t_span=ts, batch_size=R5), 1)
 print(json.dumps(dict(config="C5 GVP [1024] D=64, 100-step ODE, batch 262144", engine="bf16 (batch engine)", seconds=t,
                       action_steps_per_s=R5 * 100 / t, tflops=R5 * 100 * 6950912 / t / 1e12)), flush=True)
+
+# QGPO's shipped solver: DPM-Solver-2 singlestep, 17 function evaluations, energy-guided (fp32 batch engine per NFE)
+q.model.compute_dtype = L.F32
+Rd = 1 << 20
+condd = torch.randn(Rd, 17, device=DEV); x0d = torch.randn(Rd, 6, device=DEV)
+sc = dict(type="DPMSolver", args=dict(order=2, device=DEV, steps=17))
+t = timed(lambda: q.sample(x_0=x0d, condition=condd, guidance_scale=1.0, solver_config=sc), 1)
+print(json.dumps(dict(config="QGPO guided DPM-Solver-2, 17 NFE, %d rows" % Rd, engine="f32 batch engine (host-driven stages)", seconds=t,
+                      samples_per_s=Rd / t, action_steps_per_s=Rd * 17 / t, tflops=Rd * 17 * 3547712 / t / 1e12)), flush=True)

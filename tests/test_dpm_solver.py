@@ -1,0 +1,124 @@
+"""DPM-Solver: the oracle restatement against goldens produced by the reference's own
+DPMSolver (tests/golden/make_golden_dpm.py), and the package's DPMSolver -- every model evaluation a HIP forward
+through the C ABI -- against the same goldens on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+import golden_lib as gl
+import golden_util as gu
+import util_models as um
+from oracle import grl_oracle as O
+
+MODELS = ("small_vp_noise", "small_vp_score", "small_vp_velocity", "small_energy", "qgpo_noise")
+
+
+def _load():
+    return gu.load("dpm.npz")
+
+
+def _cases(g, name):
+    for key in sorted(g):
+        if key.startswith(name + "/o"):
+            p = key.split("/")[1].split("_")
+            # o<order> n<steps> <type: dpm solver[pp]> <method> <solver_type...> <skip...> d<denoise> [g<scale>]
+            order, steps = int(p[0][1:]), int(p[1][1:])
+            rest = "_".join(p[2:])
+            typ = "dpm_solver++" if rest.startswith("dpm_solverpp") else "dpm_solver"
+            rest = rest[len("dpm_solverpp_" if typ == "dpm_solver++" else "dpm_solver_"):]
+            assert rest.startswith("singlestep_")
+            rest = rest[len("singlestep_"):]
+            solver_type = "dpm_solver" if rest.startswith("dpm_solver_") else "taylor"
+            rest = rest[len(solver_type) + 1:]
+            skip = "time_uniform" if rest.startswith("time_uniform") else "time_quadratic"
+            gs = float(rest.split("_g")[1]) if "_g" in rest else None
+            yield key, dict(order=order, steps=steps, type=typ, method="singlestep", solver_type=solver_type,
+                            skip_type=skip, denoise=False), gs
+
+
+def close(a, b, tol, what):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(1.0, float(np.abs(b).max()))
+    err = float(np.abs(a - b).max())
+    assert err <= tol * scale, "%s: max-abs err %.3e (scale %.2e)" % (what, err, scale)
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_oracle_dpm_solver_vs_reference_golden(name):
+    g = _load()
+    kind, cfg = gl.model_zoo()[name]
+    sd = gu.weights(name)
+    path = O.Path(cfg["path"])
+    mt = cfg["model"]["type"]
+    x0, cond = gu.T(g[name + "/x0"]), gu.T(g[name + "/cond"])
+    n = 0
+    for key, kw, gs in _cases(g, name):
+        net = lambda t, x: O.intrinsic_forward(sd, t, x, cond)  # noqa: E731
+        if kind == "energy":
+            score = lambda t, x: O.guided_score(sd, mt, path, t, x, cond, gs)  # noqa: E731
+            noise_fn = lambda t, x: -score(t, x) * O._b(path.std(t), x)  # noqa: E731
+            data_fn = lambda t, x: (-O._b(path.std(t), x) * x + O._b(path.cov(t), x) * score(t, x)) / O._b(path.scale(t), x)  # noqa: E731
+        else:
+            noise_fn = lambda t, x: O.noise_head(mt, path, net(t, x), t, x)  # noqa: E731
+            data_fn = lambda t, x: O.data_head(mt, path, net(t, x), t, x)  # noqa: E731
+        with torch.enable_grad():
+            out = O.dpm_solver_integrate(path, noise_fn, data_fn, x0, **kw)
+        close(out.detach(), g[key], 2e-5, key)
+        n += 1
+    assert n >= 6
+    assert any(r.startswith(name + "/") for r in g["raises"])  # the reference's own failing option sets are recorded
+
+
+def test_orders_match_reference_schedule():
+    assert O.dpm_orders_singlestep(17, 2) == [2] * 8 + [1]          # QGPO: 8 second-order steps + 1 first-order = 17 NFE
+    assert O.dpm_orders_singlestep(10, 2) == [2] * 4 + [1, 1]
+    assert O.dpm_orders_singlestep(10, 3) == [3, 3, 3, 1]
+    from generativerl_preview_amd.numerical_methods.numerical_solvers import DPMSolver, get_solver
+    assert get_solver("DPMSolver") is DPMSolver
+    for steps in range(3, 25):
+        for order in (1, 2, 3):
+            o = DPMSolver.get_orders_for_singlestep_solver(steps, order)
+            assert o == O.dpm_orders_singlestep(steps, order) and sum(o) == steps
+
+
+def test_unsupported_options_raise_like_the_reference():
+    from generativerl_preview_amd.numerical_methods.numerical_solvers import DPMSolver
+    from generativerl_preview_amd.generative_models.diffusion_process import DiffusionProcess
+    from generativerl_preview_amd.numerical_methods.probability_path import GaussianConditionalProbabilityPath
+    dp = DiffusionProcess(GaussianConditionalProbabilityPath(gl.VP))
+    x = torch.zeros(2, 3)
+    f = lambda t, x, c: x  # noqa: E731
+    with pytest.raises(TypeError):
+        DPMSolver(order=2, device="cpu", steps=6, skip_type="logSNR").integrate(dp, f, f, x)
+    with pytest.raises(TypeError):
+        DPMSolver(order=2, device="cpu", steps=6, denoise=True).integrate(dp, f, f, x)
+    with pytest.raises(NotImplementedError):
+        DPMSolver(order=2, device="cpu", steps=6, method="multistep").integrate(dp, f, f, x)
+    # host logic with a trivial "network": matches the oracle bit for bit on the CPU
+    nf = lambda t, x, c: 0.3 * x + t[:, None]  # noqa: E731
+    got = DPMSolver(order=3, device="cpu", steps=10, solver_type="taylor").integrate(dp, nf, nf, torch.ones(2, 3), save_intermediate=True)
+    want = O.dpm_solver_integrate(O.Path(gl.VP), lambda t, x: nf(t, x, None), lambda t, x: nf(t, x, None), torch.ones(2, 3),
+                                  steps=10, order=3, solver_type="taylor")
+    close(got, want, 1e-6, "host DPM-Solver vs oracle")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", MODELS)
+def test_gpu_dpm_solver_vs_reference_golden(name):
+    DEV = "cuda:0"
+    g = _load()
+    kind, cfg, m = um.build(name, DEV)
+    x0 = torch.as_tensor(g[name + "/x0"]).to(DEV)
+    cond = torch.as_tensor(g[name + "/cond"]).to(DEV)
+    n = 0
+    for key, kw, gs in _cases(g, name):
+        sc = dict(type="DPMSolver", args=dict(device=DEV, **kw))
+        call = dict(t_span=None, x_0=x0, condition=cond, solver_config=sc)
+        if gs is not None:
+            call["guidance_scale"] = gs
+        traj = m.sample_forward_process(**call)
+        close(traj.cpu(), g[key], 2e-4, key)
+        close(m.sample(**call).cpu(), g[key][-1], 2e-4, key + " final")
+        n += 1
+    assert n >= 6
