@@ -51,6 +51,8 @@ PROTOTYPES = {
                                          _vp, _sz, _vp]),
     "grlhip_sample_sde": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp,
                                          _vp, _vp, _sz, _vp]),
+    "grlhip_sample_stages": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp,
+                                            _vp, _sz, _vp]),
     "grlhip_loss_workspace_bytes": (_sz, [_vp, _i64, ctypes.c_int]),
     "grlhip_grad_numel": (_i64, [_vp]),
     "grlhip_grad_offset": (_i64, [_vp, ctypes.c_int]),

@@ -1,6 +1,6 @@
 // One (variant, EXTRA, guided) instantiation of the bf16 persistent integrator per translation unit,
 // so the ~1 minute device compilations run in parallel.
-// Built with -DB16_VARIANT=0|1 -DB16_EXTRA=0|1 -DB16_GUIDE=0|1.
+// Built with -DB16_VARIANT=0|1 -DB16_EXTRA=0|1|2 (kernel MODE) -DB16_GUIDE=0|1.
 #include <hip/hip_runtime.h>
 
 #include "plan.hpp"
@@ -21,6 +21,6 @@ using GuideSel = GuideQgpo;
 #define B16_CAT2(a, b, c, d, e, f) a##b##c##d##e##f
 #define B16_CAT(a, b, c, d, e, f) B16_CAT2(a, b, c, d, e, f)
 void B16_CAT(b16_launch_v, B16_VARIANT, _e, B16_EXTRA, _g, B16_GUIDE)(b16::SampleArgs16& a, int blocks, hipStream_t st) {
-  hipLaunchKernelGGL((b16::k_sample_bf16<CfgSel, GuideSel, B16_NSLOT, B16_CF, B16_P, (B16_EXTRA != 0)>), dim3(blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((b16::k_sample_bf16<CfgSel, GuideSel, B16_NSLOT, B16_CF, B16_P, B16_EXTRA>), dim3(blocks), dim3(256), 0, st, a);
 }
 }  // namespace grlhip

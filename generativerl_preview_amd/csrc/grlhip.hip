@@ -275,7 +275,7 @@ int grlhip_energy_grad(const grlhip_plan* plan, const void* packed, int dtype, c
 static int sample_common(const grlhip_plan* plan, const void* packed, int dtype, const grlhip_plan* guidance,
                          const void* guidance_packed, const float* x0, const float* cond, const float* coef,
                          const float* dW, int32_t n_steps, int64_t rows, float* out_final, float* out_traj,
-                         void* workspace, size_t workspace_bytes, void* stream) {
+                         void* workspace, size_t workspace_bytes, void* stream, bool stages = false) {
   if (int rc = check_ready(plan, packed)) return rc;
   const Plan* p = plan->p;
   if (p->desc.kind != GRLHIP_NET_RESNET) return fail(GRLHIP_ERR_INVALID, "sampling needs a RESNET plan");
@@ -297,13 +297,13 @@ static int sample_common(const grlhip_plan* plan, const void* packed, int dtype,
     const bool nf = bf16_fused_ok(p), gf = g && bf16_fused_ok(g);
     if (nf)  // the persistent fused integrator (rejects pairs it has no kernel for)
       return bf16_sample(p, packed, g, guidance_packed, x0, cond, coef, dW, n_steps, rows, out_final, out_traj,
-                         workspace, workspace_bytes, st, g_err);
+                         workspace, workspace_bytes, st, g_err, stages);
     if (gf) return fail(GRLHIP_ERR_UNSUPPORTED, "bf16: this energy net only has a fused kernel but the sampler net has none; use GRLHIP_F32");
     // any other shape: the batch engine with bf16 MFMAs (both images are in the fp32 layout)
     const size_t need = grlhip_workspace_bytes(plan, guidance, rows, dtype);
     if (!workspace || workspace_bytes < need) return fail(GRLHIP_ERR_WORKSPACE, "workspace too small: need " + std::to_string(need));
     SampleCall c{x0, cond, coef, dW, out_final, out_traj, rows, n_steps};
-    batch_sample(p, (const float*)packed, g, (const float*)guidance_packed, c, (float*)workspace, st, true);
+    batch_sample(p, (const float*)packed, g, (const float*)guidance_packed, c, (float*)workspace, st, true, stages);
     HIP_TRY(hipGetLastError());
     return 0;
   }
@@ -312,10 +312,11 @@ static int sample_common(const grlhip_plan* plan, const void* packed, int dtype,
   if (!workspace || workspace_bytes < need) return fail(GRLHIP_ERR_WORKSPACE, "workspace too small: need " + std::to_string(need));
   if (!f32_engine_wave()) {
     SampleCall c{x0, cond, coef, dW, out_final, out_traj, rows, n_steps};
-    batch_sample(p, (const float*)packed, g, (const float*)guidance_packed, c, (float*)workspace, st);
+    batch_sample(p, (const float*)packed, g, (const float*)guidance_packed, c, (float*)workspace, st, false, stages);
     HIP_TRY(hipGetLastError());
     return 0;
   }
+  if (stages) return fail(GRLHIP_ERR_UNSUPPORTED, "sample_stages is not available on the per-wave engine (GRLHIP_F32_ENGINE=wave)");
   HIP_TRY(hipMemsetAsync(workspace, 0, need, st));
   SampleArgs a{};
   a.net = net_args(p, packed, false, 0);
@@ -343,6 +344,14 @@ int grlhip_sample_sde(const grlhip_plan* plan, const void* packed, int dtype, co
   if (!dW && n_steps > 0) return fail(GRLHIP_ERR_INVALID, "sample_sde needs the Brownian increment buffer dW");
   return sample_common(plan, packed, dtype, guidance, guidance_packed, x0, cond, coef, dW, n_steps, rows,
                        out_final, out_traj, workspace, workspace_bytes, stream);
+}
+
+int grlhip_sample_stages(const grlhip_plan* plan, const void* packed, int dtype, const grlhip_plan* guidance,
+                         const void* guidance_packed, const float* x0, const float* cond, const float* stage_table,
+                         int32_t n_stages, int64_t rows, float* out_final, float* out_traj, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+  return sample_common(plan, packed, dtype, guidance, guidance_packed, x0, cond, stage_table, nullptr, n_stages, rows,
+                       out_final, out_traj, workspace, workspace_bytes, stream, true);
 }
 
 size_t grlhip_loss_workspace_bytes(const grlhip_plan* plan, int64_t rows, int dtype) {

@@ -115,6 +115,25 @@ class NetPlan:
                                                float(scale), _ptr(out), rows, _ptr(ws), ws.numel(), _stream(dev)))
         return out
 
+    def sample_stages(self, packed, x0, cond, table, guidance=None, guidance_packed=None, trajectory_slots=0,
+                      dtype=L.F32):
+        """table: (n_stages, COEF_STRIDE) fp32 stage table (include/grlhip.h, grlhip_sample_stages).
+        Returns (final, traj|None); traj slot 0 is x0."""
+        rows, D = x0.shape
+        dev = x0.device
+        x0, cond = _f32c(x0, "x_0", (rows, self.x_dim)), _f32c(cond, "condition")
+        table = _f32c(table.to(dev), "stage table")
+        assert table.dim() == 2 and table.shape[1] == L.COEF_STRIDE
+        final = torch.empty(rows, D, dtype=torch.float32, device=dev)
+        traj = torch.empty(trajectory_slots, rows, D, dtype=torch.float32, device=dev) if trajectory_slots else None
+        ws = self.workspace(rows, dev, guidance, dtype)
+        g_h = guidance.handle if guidance is not None else None
+        with torch.cuda.device(dev):
+            L.check(L.lib().grlhip_sample_stages(self.handle, _ptr(packed), dtype, g_h, _ptr(guidance_packed), _ptr(x0),
+                                                 _ptr(cond), _ptr(table), table.shape[0], rows, _ptr(final), _ptr(traj),
+                                                 _ptr(ws), ws.numel(), _stream(dev)))
+        return final, traj
+
     def sample(self, packed, x0, cond, coef, dW=None, guidance=None, guidance_packed=None, trajectory_slots=0,
                dtype=L.F32):
         """coef: (n_steps, 8) fp32 table (see include/grlhip.h).  Returns (final, traj|None)."""

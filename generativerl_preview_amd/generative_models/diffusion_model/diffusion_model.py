@@ -70,7 +70,9 @@ class DiffusionModel(nn.Module):
         return self.model, self.model_type
 
     def _dpm_functions(self, guidance_scale):
-        return self.noise_function, self.data_prediction_function
+        from ..fused import AffineModelFn
+        return (AffineModelFn("noise", self.model, self.model_type, self.path, call=self.noise_function),
+                AffineModelFn("data", self.model, self.model_type, self.path, call=self.data_prediction_function))
 
     def sample_forward_process(self, t_span: torch.Tensor = None, batch_size=None, x_0=None, condition=None,
                                with_grad: bool = False, solver_config=None, noise_increments=None,

@@ -51,9 +51,13 @@ class EnergyConditionalDiffusionModel(DiffusionModel):
         return GuidedScore(self.model, self.model_type, self.energy_guidance.model, gs), "score_function"
 
     def _dpm_functions(self, guidance_scale):
+        from ..fused import AffineModelFn
         gs = 1.0 if guidance_scale is None else guidance_scale
-        return (lambda t, x, c: self.noise_function_with_energy_guidance(t, x, c, gs),
-                lambda t, x, c: self.data_prediction_function_with_energy_guidance(t, x, c, gs))
+        kw = dict(guidance=self.energy_guidance.model, guidance_scale=gs)
+        return (AffineModelFn("noise", self.model, self.model_type, self.path,
+                              call=lambda t, x, c: self.noise_function_with_energy_guidance(t, x, c, gs), **kw),
+                AffineModelFn("data", self.model, self.model_type, self.path,
+                              call=lambda t, x, c: self.data_prediction_function_with_energy_guidance(t, x, c, gs), **kw))
 
     def noise_function_with_energy_guidance(self, t, x, condition=None, guidance_scale: float = 1.0):
         """:1235-1260"""

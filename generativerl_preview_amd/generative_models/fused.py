@@ -107,3 +107,45 @@ class FusedDrift:
     # evaluation is not provided; the solvers never call it)
     def __call__(self, t, x):
         raise NotImplementedError("FusedDrift is consumed whole by ODESolver/SDESolver.integrate")
+
+
+class AffineModelFn:
+    """A solver-facing model function that is affine in (net, x, dE/dx):
+        m(t, x, c) = cn(t) net(t, x, c) + cx(t) x + cg(t) dE/dx(t, x, c).
+    Every noise / data-prediction function the reference hands to DPMSolver has this form (head conversions
+    of model_functions/*.py, guided variants energy_conditional_diffusion_model.py:1235-1306).  Callable like
+    the reference closure (host-driven evaluation: HIP forward + torch algebra), and carrying the three scalars
+    so that DPMSolver can fold whole stages into ``grlhip_sample_stages``."""
+
+    def __init__(self, kind, model, model_type, path, guidance=None, guidance_scale=0.0, call=None):
+        assert kind in ("noise", "data")
+        self.kind, self.model, self.model_type, self.path = kind, model, model_type, path
+        self.guidance, self.guidance_scale, self._call = guidance, float(guidance_scale), call
+
+    def __call__(self, t, x, condition=None):
+        return self._call(t, x, condition)
+
+    def coefficients(self, t):
+        """t: 0-dim fp32 CPU tensor -> (cn, cx, cg) as Python floats."""
+        p, mt = self.path, self.model_type
+        t = t.reshape(1).to(torch.float32)
+        sig, sc, cov = p.std(t), p.scale(t), p.covariance(t)
+        if self.guidance is not None:
+            # score_g = hp net + hq x + scale dE/dx; noise_g = -std score_g; data_g = (-std x + cov score_g) / scale
+            hp, hq = _head_to_score(mt, p, t)
+            if self.kind == "noise":
+                cn, cx, cg = -sig * hp, -sig * hq, -sig * self.guidance_scale
+            else:
+                cn, cx, cg = cov * hp / sc, (-sig + cov * hq) / sc, cov * self.guidance_scale / sc
+            return float(cn), float(cx), float(cg)
+        one, zero = torch.ones_like(t), torch.zeros_like(t)
+        f, g2 = p.drift_coefficient(t), p.diffusion_squared(t)
+        if self.kind == "noise":      # NoiseFunction.forward, noise_function.py:62-78
+            cn, cx = {"noise_function": (one, zero), "score_function": (-sig, zero),
+                      "velocity_function": (2.0 * sig / g2, -f * 2.0 * sig / g2),
+                      "data_prediction_function": (-sc / sig, one / sig)}[mt]
+        else:                         # DataPredictionFunction.forward, data_prediction_function.py:62-84 (as written)
+            cn, cx = {"noise_function": (-sig / sc, one / sc), "score_function": (cov / sc, -sig / sc),
+                      "velocity_function": (-2.0 * cov / g2 / sc, (f * 2.0 * cov / g2 + 1.0) / sc),
+                      "data_prediction_function": (one, zero)}[mt]
+        return float(cn), float(cx), 0.0

@@ -33,6 +33,7 @@ class DPMSolver:
         self.denoise = denoise
         self.device = device
         self.nfe = 0
+        self.fused = True  # orders <= 2 on an affine model function: all stages in one grlhip_sample_stages call
 
     # ---- dpm_solver.py:127-161
     def get_time_steps(self, t_T, t_0, N):
@@ -153,6 +154,9 @@ class DPMSolver:
         t_0, t_T = 0.00001, float(dp.t_max)
         orders = self.get_orders_for_singlestep_solver(steps=steps, order=self.order)
         ts = self.get_time_steps(t_T=t_T, t_0=t_0, N=steps)
+        fn = data_prediction_function if plus else noise_function
+        if self.fused and hasattr(fn, "coefficients") and max(orders) <= 2 and x.is_cuda and x.dim() == 2:
+            return self._integrate_fused(dp, fn, x, condition, orders, ts, save_intermediate)
         x_list = [x.clone()] if save_intermediate else None
         with torch.no_grad():
             i = 0
@@ -166,3 +170,55 @@ class DPMSolver:
                     x_list.append(x.clone())
                 i += o
         return torch.stack(x_list, dim=0) if save_intermediate else x
+
+    def _integrate_fused(self, dp, fn, x, condition, orders, ts, save_intermediate):
+        """Orders 1-2: every stage is `m = cn net + cx x + cg dE/dx; x <- P x + Q xs + R m + W ms` (include/grlhip.h,
+        grlhip_sample_stages); the same scalars as the host-driven path, tabulated once."""
+        from ... import _lib as L
+        plus, high = self.use_dpm_solver_plus_plus, self.default_high_order_solvers
+        lam, la, sig = dp.HalfLogSNR, dp.log_scale, dp.std
+        rows = []
+
+        def stage(tau, P, Q, R, W, save, emit):
+            cn, cx, cg = fn.coefficients(tau)
+            rows.append([float(tau), float(P), float(Q), float(R), float(W), cn, cx, cg, float(save), float(emit), 0.0, 0.0])
+
+        i = 0
+        for k, o in enumerate(orders):
+            s, t = ts[i], ts[i + o]
+            h = lam(t) - lam(s)
+            emit = k + 1 if save_intermediate else -1
+            keep = (sig(t) / sig(s)) if plus else torch.exp(la(t) - la(s))                     # coefficient of x_s
+            lead = (torch.exp(la(t)) * torch.expm1(-h)) if plus else (sig(t) * torch.expm1(h))  # coefficient of m_s
+            if o == 1:
+                stage(s, keep, 0.0, -lead, 0.0, 0, emit)
+            else:
+                r1 = (lam(ts[i + 1]) - lam(s)) / h
+                s1 = dp.InverseHalfLogSNR(lam(s) + r1 * h).reshape(-1)[0]
+                if plus:
+                    stage(s, sig(s1) / sig(s), 0.0, -(torch.exp(la(s1)) * torch.expm1(-r1 * h)), 0.0, 1, -1)
+                    if high:
+                        c = (0.5 / r1) * torch.exp(la(t)) * torch.expm1(-h)      # x_t = .. - c (m1 - m)
+                        stage(s1, 0.0, keep, -c, -lead + c, 0, emit)
+                    else:
+                        c = (1.0 / r1) * torch.exp(la(t)) * ((torch.exp(-h) - 1.0) / h + 1.0)  # x_t = .. + c (m1 - m)
+                        stage(s1, 0.0, keep, c, -lead - c, 0, emit)
+                else:
+                    stage(s, torch.exp(la(s1) - la(s)), 0.0, -(sig(s1) * torch.expm1(r1 * h)), 0.0, 1, -1)
+                    if high:
+                        c = (0.5 / r1) * sig(t) * torch.expm1(h)
+                    else:
+                        c = (1.0 / r1) * sig(t) * ((torch.exp(h) - 1.0) / h - 1.0)
+                    stage(s1, 0.0, keep, -c, -lead + c, 0, emit)
+            i += o
+        self.nfe += len(rows)
+        table = torch.tensor(rows, dtype=torch.float32)
+        assert table.shape[1] == L.COEF_STRIDE
+        m = fn.model
+        dtype = m.compute_dtype
+        g_plan = g_packed = None
+        if fn.guidance is not None:
+            g_plan, g_packed = fn.guidance.plan, fn.guidance.packed(dtype)
+        final, traj = m.plan.sample_stages(m.packed(dtype), x, condition, table, guidance=g_plan, guidance_packed=g_packed,
+                                           trajectory_slots=len(orders) + 1 if save_intermediate else 0, dtype=dtype)
+        return traj if save_intermediate else final

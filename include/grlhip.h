@@ -154,6 +154,25 @@ int grlhip_sample_sde(const grlhip_plan* plan, const void* packed, int dtype,
                       int32_t n_steps, int64_t rows, float* out_final, float* out_traj,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* Replaces: DPMSolver.integrate, method "singlestep", orders 1-2
+ * (grl/numerical_methods/numerical_solvers/dpm_solver.py:250-391,854-904) and any other solver whose step is a
+ * sequence of STAGES, each one evaluation of the network (and energy gradient) followed by an affine update with
+ * one saved state and one saved model output.  stage_table[n_stages][GRLHIP_COEF_STRIDE], a HOST-computed DEVICE
+ * table with the layout
+ *   [0] tau   time fed to the network(s) at this stage
+ *   [5] cn, [6] cx, [7] cg     m = cn*net(tau,x,c) + cx*x + cg*dE/dx(tau,x,c)   (the solver's "model" output: the
+ *                              head conversion and the energy guidance folded into three scalars)
+ *   [1] P, [2] Q, [3] R, [4] W x_new = P*x + Q*xs + R*m + W*ms
+ *   [8] save  != 0: afterwards xs = x (the state BEFORE the update), ms = m       (xs = ms = 0 initially)
+ *   [9] emit  >= 0: out_traj[emit] = x_new (stored as float; only if out_traj != NULL; slot 0 = x0)
+ *   [10], [11] reserved (0).
+ * One call runs every stage of every row (one launch on the fused bf16 path). */
+int grlhip_sample_stages(const grlhip_plan* plan, const void* packed, int dtype,
+                         const grlhip_plan* guidance, const void* guidance_packed,
+                         const float* x0, const float* cond, const float* stage_table, int32_t n_stages,
+                         int64_t rows, float* out_final, float* out_traj,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 /* Workspace bytes for grlhip_loss_fwd_bwd over `rows` rows. */
 size_t grlhip_loss_workspace_bytes(const grlhip_plan* plan, int64_t rows, int dtype);
 /* Number of fp32 elements of the flat gradient buffer (all parameters in param_info order). */

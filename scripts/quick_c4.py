@@ -46,5 +46,14 @@ Rd = 1 << 20
 condd = torch.randn(Rd, 17, device=DEV); x0d = torch.randn(Rd, 6, device=DEV)
 sc = dict(type="DPMSolver", args=dict(order=2, device=DEV, steps=17))
 t = timed(lambda: q.sample(x_0=x0d, condition=condd, guidance_scale=1.0, solver_config=sc), 1)
-print(json.dumps(dict(config="QGPO guided DPM-Solver-2, 17 NFE, %d rows" % Rd, engine="f32 batch engine (host-driven stages)", seconds=t,
+print(json.dumps(dict(config="QGPO guided DPM-Solver-2, 17 NFE, %d rows" % Rd, engine="f32 batch engine (grlhip_sample_stages)", seconds=t,
                       samples_per_s=Rd / t, action_steps_per_s=Rd * 17 / t, tflops=Rd * 17 * 3547712 / t / 1e12)), flush=True)
+
+q.model.compute_dtype = L.BF16
+Rb = 1 << 22
+condb = torch.randn(Rb, 17, device=DEV); x0b = torch.randn(Rb, 6, device=DEV)
+for typ in ("dpm_solver", "dpm_solver++"):
+    scb = dict(type="DPMSolver", args=dict(order=2, device=DEV, steps=17, type=typ))
+    t = timed(lambda: q.sample(x_0=x0b, condition=condb, guidance_scale=1.0, solver_config=scb), 2)
+    print(json.dumps(dict(config="QGPO guided DPM-Solver-2 (%s), 17 NFE, %d rows" % (typ, Rb), engine="bf16 persistent integrator (stage mode)",
+                          seconds=t, samples_per_s=Rb / t, action_steps_per_s=Rb * 17 / t, tflops=Rb * 17 * 3547712 / t / 1e12)), flush=True)

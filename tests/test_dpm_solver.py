@@ -122,3 +122,50 @@ def test_gpu_dpm_solver_vs_reference_golden(name):
         close(m.sample(**call).cpu(), g[key][-1], 2e-4, key + " final")
         n += 1
     assert n >= 6
+
+
+@pytest.mark.gpu
+def test_gpu_fused_stages_equal_host_driven_stages_and_bf16_runs_in_the_persistent_kernel():
+    """Orders <= 2 go through grlhip_sample_stages (one call; the persistent bf16 integrator for the QGPO shapes):
+    same result as the host-driven evaluation in fp32, within the bf16 tolerance of the oracle in bf16."""
+    from generativerl_preview_amd import _lib as L
+    from generativerl_preview_amd.numerical_methods.numerical_solvers import DPMSolver
+    import generativerl_preview_amd.engine as engine
+    DEV = "cuda:0"
+    kind, cfg, m = um.build("qgpo_noise", DEV)
+    sd = gu.weights("qgpo_noise")
+    gen = torch.Generator().manual_seed(31)
+    x0, cond = torch.randn(700, 6, generator=gen), torch.randn(700, 17, generator=gen)
+    calls = []
+    orig = engine.NetPlan.sample_stages
+    engine.NetPlan.sample_stages = lambda self, *a, **k: (calls.append(k.get("dtype")), orig(self, *a, **k))[1]
+    try:
+        for typ in ("dpm_solver++", "dpm_solver"):
+            args = dict(order=2, device=DEV, steps=17, type=typ)
+            fused = m.sample_forward_process(x_0=x0.to(DEV), condition=cond.to(DEV), guidance_scale=1.0,
+                                             solver_config=dict(type="DPMSolver", args=args))
+            assert len(calls) >= 1
+            solver = DPMSolver(**args)
+            solver.fused = False
+            nf, df = m._dpm_functions(1.0)
+            host = solver.integrate(m.diffusion_process, nf, df, x0.to(DEV), cond.to(DEV), save_intermediate=True)
+            assert solver.nfe == 17
+            close(fused.cpu(), host.cpu(), 2e-5, "fused vs host-driven " + typ)
+        # bf16: the persistent integrator; dpm_solver++ keeps the states O(1)
+        path, mt = O.Path(cfg["path"]), cfg["model"]["type"]
+        score = lambda t, x: O.guided_score(sd, mt, path, t, x, cond, 1.0)  # noqa: E731
+        noise_fn = lambda t, x: -score(t, x) * O._b(path.std(t), x)  # noqa: E731
+        data_fn = lambda t, x: (-O._b(path.std(t), x) * x + O._b(path.cov(t), x) * score(t, x)) / O._b(path.scale(t), x)  # noqa: E731
+        with torch.enable_grad():
+            want = O.dpm_solver_integrate(path, noise_fn, data_fn, x0, steps=17, order=2, type="dpm_solver++")
+        m.model.compute_dtype = L.BF16
+        n0 = len(calls)
+        got = m.sample_forward_process(x_0=x0.to(DEV), condition=cond.to(DEV), guidance_scale=1.0,
+                                       solver_config=dict(type="DPMSolver", args=dict(order=2, device=DEV, steps=17, type="dpm_solver++")))
+        assert calls[n0:] == [L.BF16]
+        close(got.cpu(), want.detach(), 2e-2, "bf16 fused DPM-Solver++ trajectory")
+        close(m.sample(x_0=x0.to(DEV), condition=cond.to(DEV), guidance_scale=1.0,
+                       solver_config=dict(type="DPMSolver", args=dict(order=2, device=DEV, steps=17, type="dpm_solver++"))).cpu(),
+              want[-1].detach(), 2e-2, "bf16 fused DPM-Solver++ final")
+    finally:
+        engine.NetPlan.sample_stages = orig
