@@ -398,4 +398,28 @@ int grlhip_loss_fwd_bwd(const grlhip_plan* plan, const void* packed, int dtype, 
   return 0;
 }
 
+int grlhip_cep_loss_fwd_bwd(const grlhip_plan* plan, const void* packed, int dtype, const float* t, const float* x_t,
+                            const float* cond, const float* logits0, int32_t group_size, const float* group_weight,
+                            float* loss_groups, float* grad_flat, int64_t rows, void* workspace, size_t workspace_bytes,
+                            void* stream) {
+  if (int rc = check_ready(plan, packed)) return rc;
+  const Plan* p = plan->p;
+  if (p->desc.kind != GRLHIP_NET_CONCAT_MLP || p->train_fwd.empty())
+    return fail(GRLHIP_ERR_UNSUPPORTED, "cep_loss_fwd_bwd needs a CONCAT_MLP plan");
+  if (dtype != GRLHIP_F32) return fail(GRLHIP_ERR_UNSUPPORTED, "cep_loss_fwd_bwd: only GRLHIP_F32 is implemented");
+  if (f32_engine_wave()) return fail(GRLHIP_ERR_UNSUPPORTED, "cep_loss_fwd_bwd runs on the batch engine only (unset GRLHIP_F32_ENGINE)");
+  if (group_size < 1 || group_size > TRAIN_CHUNK_ROWS) return fail(GRLHIP_ERR_INVALID, "group_size must be in [1, 65536]");
+  if (rows < 0 || rows % group_size) return fail(GRLHIP_ERR_INVALID, "rows must be a multiple of group_size");
+  if (rows == 0) return 0;
+  if (!t || !x_t || !logits0 || !loss_groups) return fail(GRLHIP_ERR_INVALID, "null t/x_t/logits0/loss_groups");
+  if ((p->desc.cond_dim > 0) != (cond != nullptr))
+    return fail(GRLHIP_ERR_INVALID, "condition pointer does not match the plan's cond_dim");
+  const size_t need = grlhip_loss_workspace_bytes(plan, rows, dtype);
+  if (!workspace || workspace_bytes < need) return fail(GRLHIP_ERR_WORKSPACE, "workspace too small: need " + std::to_string(need));
+  CepCall c{t, x_t, cond, logits0, group_weight, loss_groups, grad_flat, rows, group_size};
+  cep_step(p, (const float*)packed, c, (float*)workspace, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 }  // extern "C"

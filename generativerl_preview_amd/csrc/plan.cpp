@@ -290,6 +290,53 @@ Plan* build_plan(const grlhip_net_desc& d, std::string& err) {
     const LinearDesc l1 = p->linears[lin[0]];
     int lx = b.add_matrix(d.x_dim, l1.N, l1.p_w, -1, d.t_dim, l1.K, 1);  // (W_1[:, x cols])^T
     b.linear(G, lx, dz[0], p->gradx_off, -1, 0);
+
+    // ---- training programs (CEP energy_guidance_loss, energy_conditional_diffusion_model.py:1308-1394):
+    // forward keeping every pre-activation; backward from d loss / d f (tr_gout, one feature) to every
+    // weight / bias gradient and to the Fourier features (tr_gtc)
+    {
+      Builder t{p};
+      t.woff = b.woff;
+      auto& TF = p->train_fwd;
+      auto& TB = p->train_bwd;
+      p->tr_temb = t.alloc(K0);
+      p->tr_x = p->tr_temb + d.t_dim;
+      p->tr_c = d.cond_dim > 0 ? p->tr_x + d.x_dim : -1;
+      std::vector<int> tz(L), ta(L);
+      for (int i = 0; i < L; ++i) { tz[i] = t.alloc(d.hidden[i]); ta[i] = t.alloc(d.hidden[i]); }
+      p->tr_out = t.alloc(1);
+      p->tr_gout = t.alloc(1);
+      const int hmax = *std::max_element(d.hidden, d.hidden + L);
+      const int g_a = t.alloc(hmax), g_z = t.alloc(hmax);
+      p->tr_gtc = t.alloc(d.t_dim);
+      int tin = p->tr_temb;
+      for (int i = 0; i < L; ++i) { t.linear(TF, lin[i], tin, ta[i], -1, F_SILU_OUT | F_SAVE_PRE, tz[i]); tin = ta[i]; }
+      t.linear(TF, lin[L], tin, p->tr_out, -1, 0);
+      auto dw = [&](int li, int dzo, int ino) {
+        const LinearDesc l = p->linears[li];
+        Op o{};
+        o.type = OP_DW; o.K = l.K; o.N = l.N; o.w = (int32_t)p->params[l.p_w].grad_off;
+        o.b = l.p_b >= 0 ? (int32_t)p->params[l.p_b].grad_off : -1;
+        o.in = ino; o.add = dzo; o.out = -1; o.pre = l.K; o.lin = li;
+        TB.push_back(o);
+      };
+      dw(lin[L], p->tr_gout, ta[L - 1]);
+      t.linear(TB, lw, p->tr_gout, g_a, -1, 0);                       // da_L = w_last * df
+      for (int i = L - 1; i >= 0; --i) {
+        t.eltwise(TB, OP_SILU_BWD, d.hidden[i], tz[i], g_z, g_a);     // dz_i = da_i * silu'(z_i)
+        dw(lin[i], g_z, i ? ta[i - 1] : p->tr_temb);
+        const LinearDesc li = p->linears[lin[i]];
+        if (i) {
+          int lt = t.add_matrix(li.K, li.N, li.p_w, -1, 0, li.K, 1);  // W_i^T
+          t.linear(TB, lt, g_z, g_a, -1, 0);
+        } else {
+          int lt = t.add_matrix(d.t_dim, li.N, li.p_w, -1, 0, li.K, 1);  // (W_1[:, t_emb cols])^T
+          t.linear(TB, lt, g_z, p->tr_gtc, -1, 0);
+        }
+      }
+      p->train_slab_features = up(t.bump, 2);
+      b.woff = t.woff;
+    }
   } else {
     err = "unknown net kind";
     delete p; return nullptr;

@@ -96,3 +96,33 @@ class EnergyConditionalDiffusionModel(DiffusionModel):
         p, q = _head_to_score(self.model_type, self.path, t)
         return p[:, None] * net + q[:, None] * x + self.energy_guidance.calculate_energy_guidance(
             t, x, condition, guidance_scale)
+
+    def energy_guidance_loss(self, x, condition=None, t=None, noise=None, energy=None):
+        """:1308-1394, contrastive energy prediction.  x: (B, K, D) support actions per state, condition: (B, C).
+        The energy net's forward, the group softmax cross-entropy and the backward run in one HIP library call;
+        ``self.energy_model`` (any module, evaluated without grad as in the reference) supplies the energies unless
+        ``energy`` (B, K) is given.  Supersets: ``t`` (B,) and ``noise`` (B, K, D) pin the random draws, made in
+        the reference's order otherwise (t first, then the noise of direct_sample)."""
+        from ..model_functions.losses import fused_cep_loss
+        if not torch.is_tensor(x) or x.dim() != 3:
+            raise NotImplementedError("energy_guidance_loss: x must be a (B, K, D) tensor (dict-typed states are out of scope)")
+        B, K, D = x.shape
+        if K == 1:  # the reference's squeeze(dim=-1) drops the group axis and LogSoftmax(dim=1) raises (:1380, :1389)
+            raise IndexError("Dimension out of range (expected to be in range of [-1, 0], but got 1)")
+        eps = 1e-3
+        if t is None:
+            t = torch.rand((B,), device=x.device) * (1.0 - eps) + eps
+        x_flat = x.reshape(B * K, D)
+        cond_rep = None if condition is None else condition.unsqueeze(1).expand(B, K, *condition.shape[1:]).reshape(
+            B * K, *condition.shape[1:])
+        if energy is None:
+            with torch.no_grad():
+                energy = self.energy_model(x_flat, cond_rep) if cond_rep is not None else self.energy_model(x_flat)
+        energy = energy.detach().reshape(B, K)
+        if noise is None:
+            noise = torch.randn_like(x)
+        t_rep = t.unsqueeze(1).expand(B, K)
+        pth = self.path
+        x_t = pth.scale(t_rep)[..., None] * x + pth.std(t_rep)[..., None] * noise
+        return fused_cep_loss(self.energy_guidance.model, t_rep.reshape(B * K), x_t.reshape(B * K, D), cond_rep,
+                              (energy * self.alpha).reshape(B * K), K)

@@ -163,3 +163,51 @@ def fused_loss(model, t, x_t, cond, alpha, beta, target, average=True):
     named = model._named()
     params = [named[n] for n, _ in model.plan.params]
     return _FusedLoss.apply(model, t, x_t, cond, alpha, beta, target, average, *params)
+
+
+class _FusedCepLoss(torch.autograd.Function):
+    """Contrastive energy prediction: energy-guidance net forward + group softmax cross-entropy + backward in ONE
+    library call (grlhip_cep_loss_fwd_bwd); the mean over groups is returned."""
+
+    @staticmethod
+    def forward(ctx, model, t, x_t, cond, logits0, group_size, *params):
+        plan = model.plan
+        R, dev = x_t.shape[0], x_t.device
+        G = R // group_size
+        lib = L.lib()
+        loss_groups = torch.empty(G, dtype=torch.float32, device=dev)
+        need_grad = any(p.requires_grad for p in params)
+        flat = torch.zeros(lib.grlhip_grad_numel(plan.handle), dtype=torch.float32, device=dev) if need_grad else None
+        gw = torch.full((G,), 1.0 / G, dtype=torch.float32, device=dev) if need_grad else None
+        t, x_t, cond = _f32c(t, "t", (R,)), _f32c(x_t, "x_t", (R, plan.x_dim)), _f32c(cond, "condition")
+        logits0 = _f32c(logits0, "logits0", (R,))
+        need = lib.grlhip_loss_workspace_bytes(plan.handle, R, L.F32)
+        ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            L.check(lib.grlhip_cep_loss_fwd_bwd(plan.handle, _ptr(model.packed(L.F32)), L.F32, _ptr(t), _ptr(x_t),
+                                                _ptr(cond), _ptr(logits0), group_size, _ptr(gw), _ptr(loss_groups),
+                                                _ptr(flat), R, _ptr(ws), ws.numel(), _stream(dev)))
+        ctx.model, ctx.flat = model, flat
+        return loss_groups.mean()
+
+    @staticmethod
+    def backward(ctx, gout):
+        plan = ctx.model.plan
+        named = ctx.model._named()
+        grads = []
+        for i, (name, shape) in enumerate(plan.params):
+            p = named[name]
+            if p.requires_grad and ctx.flat is not None:
+                off = L.lib().grlhip_grad_offset(plan.handle, i)
+                grads.append((ctx.flat[off:off + p.numel()] * gout).view(p.shape))
+            else:
+                grads.append(None)
+        return (None, None, None, None, None, None, *grads)
+
+
+def fused_cep_loss(model, t, x_t, cond, logits0, group_size):
+    """model: the energy guidance's IntrinsicModel (ConcatenateMLP).  Rows are B groups of ``group_size``
+    consecutive support actions; returns -mean_b sum_k softmax(logits0)_bk log_softmax(f(t, x_t, c))_bk."""
+    named = model._named()
+    params = [named[n] for n, _ in model.plan.params]
+    return _FusedCepLoss.apply(model, t, x_t, cond, logits0, group_size, *params)

@@ -192,6 +192,19 @@ int grlhip_loss_fwd_bwd(const grlhip_plan* plan, const void* packed, int dtype, 
                         float* grad_flat, int64_t rows, void* workspace, size_t workspace_bytes,
                         void* stream);
 
+/* Replaces: the energy-guidance network's forward + autograd backward inside
+ * EnergyConditionalDiffusionModel.energy_guidance_loss (contrastive energy prediction,
+ * grl/generative_models/diffusion_model/energy_conditional_diffusion_model.py:1354-1394) for a CONCAT_MLP plan.
+ * Rows come in groups of `group_size` consecutive support actions of one state (x.reshape(B*K, D) order);
+ *   f = net(t, x_t, c);  loss_g = -sum_k softmax(logits0)_gk * log_softmax(f)_gk     (both over the group)
+ * with logits0[R] = alpha * energy_model(x_0, c) supplied by the caller (detached in the reference).
+ * loss_groups[R/group_size] receives loss_g; grad_flat (+=, may be NULL) receives
+ * sum_g group_weight[g] * d loss_g / d theta (group_weight NULL = 1).  Workspace: grlhip_loss_workspace_bytes. */
+int grlhip_cep_loss_fwd_bwd(const grlhip_plan* plan, const void* packed, int dtype, const float* t,
+                            const float* x_t, const float* cond, const float* logits0, int32_t group_size,
+                            const float* group_weight, float* loss_groups, float* grad_flat, int64_t rows,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

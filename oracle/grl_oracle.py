@@ -556,3 +556,21 @@ def dpm_solver_integrate(path, noise_fn, data_fn, x, steps=20, order=2, type="dp
         x = data_fn(torch.ones(B) * t_0, x)
         xs[-1] = x.clone()
     return torch.stack(xs, 0)
+
+
+# ----------------------------------------------------------------------------- CEP
+def energy_guidance_loss(sd, path, x, cond, energy, t, noise, alpha=1.0, pre="energy_guidance.model."):
+    """EnergyConditionalDiffusionModel.energy_guidance_loss,
+    diffusion_model/energy_conditional_diffusion_model.py:1308-1394 (contrastive energy prediction).
+    x (B, K, D) support actions, cond (B, C) | None, energy (B, K) = energy_model(x, cond) detached,
+    t (B,) and noise (B, K, D) = the reference's draws (:1326 and diffusion_process.py:956).
+    sd values that require grad receive the gradient when the result is back-propagated."""
+    B, K, D = x.shape
+    t_rep = torch.stack([t] * K, dim=1)                                               # :1327
+    x_t = path.scale(t_rep)[..., None] * x + path.std(t_rep)[..., None] * noise       # :1354
+    c_rep = None if cond is None else torch.stack([cond] * K, dim=1).reshape(B * K, -1)  # :1368-1372
+    f = intrinsic_forward(sd, t_rep.reshape(B * K), x_t.reshape(B * K, D), c_rep, pre=pre,
+                          backbone="ConcatenateMLP").reshape(B, K)                    # :1375-1380
+    log_p = torch.log_softmax(f, dim=1)                                               # :1389
+    p0 = torch.softmax(energy * alpha, dim=1)                                         # :1390
+    return -torch.mean(torch.sum(p0 * log_p, dim=-1))                                 # :1391-1393
