@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("GRLHIP_LIB") or os.path.join(_HERE, "libgrlhip.so")
 
 MAX_HIDDEN = 8
 F32, BF16 = 0, 1
-NET_RESNET, NET_CONCAT_MLP = 0, 1
+NET_RESNET, NET_CONCAT_MLP, NET_QNET = 0, 1, 2
 COEF_STRIDE = 12
 
 

@@ -198,8 +198,9 @@ int grlhip_pack_weights(const grlhip_plan* plan, const void* const* params, int 
     hipLaunchKernelGGL(k_pack_f32, dim3(blocks), dim3(256), 0, st, a);
   }
   const int half = p->desc.t_dim / 2;
-  hipLaunchKernelGGL(k_copy_pad_f32, dim3(1), dim3(64), 0, st, (const float*)params[0], dst + p->fourier_off, half,
-                     (int)(p->packed_floats - p->fourier_off));
+  if (half)
+    hipLaunchKernelGGL(k_copy_pad_f32, dim3(1), dim3(64), 0, st, (const float*)params[0], dst + p->fourier_off, half,
+                       (int)(p->packed_floats - p->fourier_off));
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -221,7 +222,9 @@ int grlhip_net_forward(const grlhip_plan* plan, const void* packed, int dtype, c
   if (int rc = check_ready(plan, packed)) return rc;
   const Plan* p = plan->p;
   if (rows <= 0) return 0;
-  if (!t || !x || !out) return fail(GRLHIP_ERR_INVALID, "null t/x/out");
+  const bool qnet = p->desc.kind == GRLHIP_NET_QNET;
+  if ((!t && !qnet) || !x || !out) return fail(GRLHIP_ERR_INVALID, "null t/x/out");
+  if (qnet && f32_engine_wave()) return fail(GRLHIP_ERR_UNSUPPORTED, "QNET plans run on the batch engine only (unset GRLHIP_F32_ENGINE)");
   if ((p->desc.cond_dim > 0) != (cond != nullptr))
     return fail(GRLHIP_ERR_INVALID, "condition pointer does not match the plan's cond_dim");
   if (dtype != GRLHIP_F32) return fail(GRLHIP_ERR_UNSUPPORTED, "net_forward: only GRLHIP_F32 is implemented");
@@ -366,12 +369,15 @@ int grlhip_loss_fwd_bwd(const grlhip_plan* plan, const void* packed, int dtype, 
                         size_t workspace_bytes, void* stream) {
   if (int rc = check_ready(plan, packed)) return rc;
   const Plan* p = plan->p;
-  if (p->desc.kind != GRLHIP_NET_RESNET || !p->d_train_fwd)
-    return fail(GRLHIP_ERR_UNSUPPORTED, "loss_fwd_bwd needs a RESNET plan");
-  if (p->desc.out_dim != p->desc.x_dim) return fail(GRLHIP_ERR_INVALID, "loss_fwd_bwd needs out_dim == x_dim");
+  const bool qnet = p->desc.kind == GRLHIP_NET_QNET;
+  if ((p->desc.kind != GRLHIP_NET_RESNET && !qnet) || p->train_fwd.empty())
+    return fail(GRLHIP_ERR_UNSUPPORTED, "loss_fwd_bwd needs a RESNET or QNET plan");
+  if (!qnet && p->desc.out_dim != p->desc.x_dim) return fail(GRLHIP_ERR_INVALID, "loss_fwd_bwd needs out_dim == x_dim");
   if (dtype != GRLHIP_F32) return fail(GRLHIP_ERR_UNSUPPORTED, "loss_fwd_bwd: only GRLHIP_F32 is implemented");
+  if (qnet && f32_engine_wave()) return fail(GRLHIP_ERR_UNSUPPORTED, "QNET plans run on the batch engine only (unset GRLHIP_F32_ENGINE)");
   if (rows <= 0) return 0;
-  if (!t || !x_t || !alpha || !beta || !target || !loss_rows) return fail(GRLHIP_ERR_INVALID, "null t/x_t/alpha/beta/target/loss_rows");
+  if (qnet) { t = nullptr; beta = nullptr; }
+  if ((!t && !qnet) || !x_t || !alpha || (!beta && !qnet) || !target || !loss_rows) return fail(GRLHIP_ERR_INVALID, "null t/x_t/alpha/beta/target/loss_rows");
   if ((p->desc.cond_dim > 0) != (cond != nullptr))
     return fail(GRLHIP_ERR_INVALID, "condition pointer does not match the plan's cond_dim");
   const size_t need = grlhip_loss_workspace_bytes(plan, rows, dtype);

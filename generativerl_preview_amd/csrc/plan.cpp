@@ -63,7 +63,9 @@ struct Builder {
 
 Plan* build_plan(const grlhip_net_desc& d, std::string& err) {
   if (d.n_hidden < 1 || d.n_hidden > GRLHIP_MAX_HIDDEN) { err = "n_hidden must be in [1, 8]"; return nullptr; }
-  if (d.x_dim < 1 || d.out_dim < 1 || d.t_dim < 2 || (d.t_dim & 1)) { err = "x_dim/out_dim >= 1 and even t_dim >= 2 required"; return nullptr; }
+  const bool qnet = d.kind == GRLHIP_NET_QNET;
+  if (qnet && d.t_dim != 0) { err = "a QNET plan has no time input: t_dim must be 0"; return nullptr; }
+  if (d.x_dim < 1 || d.out_dim < 1 || (!qnet && (d.t_dim < 2 || (d.t_dim & 1)))) { err = "x_dim/out_dim >= 1 and even t_dim >= 2 required"; return nullptr; }
   if (d.cond_dim < 0) { err = "cond_dim < 0"; return nullptr; }
   for (int i = 0; i < d.n_hidden; ++i)
     if (d.hidden[i] < 1) { err = "hidden sizes must be positive"; return nullptr; }
@@ -71,7 +73,7 @@ Plan* build_plan(const grlhip_net_desc& d, std::string& err) {
   Plan* p = new Plan();
   p->desc = d;
   Builder b{p};
-  b.add_param("t_encoder.W", d.t_dim / 2, 0);
+  if (!qnet) b.add_param("t_encoder.W", d.t_dim / 2, 0);
 
   if (d.kind == GRLHIP_NET_RESNET) {
     const int L = d.n_hidden;
@@ -245,8 +247,9 @@ Plan* build_plan(const grlhip_net_desc& d, std::string& err) {
       p->train_slab_features = up(t.bump, 2);
       b.woff = t.woff;
     }
-  } else if (d.kind == GRLHIP_NET_CONCAT_MLP) {
+  } else if (d.kind == GRLHIP_NET_CONCAT_MLP || qnet) {
     const int L = d.n_hidden;
+    const int ACT = qnet ? F_RELU_OUT : F_SILU_OUT, ACT_BWD = qnet ? OP_RELU_BWD : OP_SILU_BWD;
     const int K0 = d.t_dim + d.x_dim + d.cond_dim;
     if (d.out_dim != 1) { err = "CONCAT_MLP energy nets must have out_dim == 1"; delete p; return nullptr; }
     p->temb_off = b.alloc(K0);  // [t_emb | x | c] contiguous (concat order intrinsic_model.py:69)
@@ -266,12 +269,12 @@ Plan* build_plan(const grlhip_net_desc& d, std::string& err) {
     // forward (energy value)
     auto& F = p->fwd;
     int in = p->temb_off;
-    for (int i = 0; i < L; ++i) { b.linear(F, lin[i], in, ab[i], -1, F_SILU_OUT); in = ab[i]; }
+    for (int i = 0; i < L; ++i) { b.linear(F, lin[i], in, ab[i], -1, ACT); in = ab[i]; }
     b.linear(F, lin[L], in, p->out_off, -1, 0);
-    // gradient program: pre-activations, then dE/dx
+    // gradient program (energy nets only): pre-activations, then dE/dx
     auto& G = p->grad;
     in = p->temb_off;
-    for (int i = 0; i < L; ++i) {
+    for (int i = 0; i < L && !qnet; ++i) {
       b.linear(G, lin[i], in, zb[i], -1, 0);
       if (i + 1 < L) { b.eltwise(G, OP_SILU, d.hidden[i], zb[i], ab[i]); in = ab[i]; }
     }
@@ -280,16 +283,18 @@ Plan* build_plan(const grlhip_net_desc& d, std::string& err) {
     const LinearDesc last = p->linears[lin[L]];
     int lw = b.add_matrix(d.hidden[L - 1], 1, last.p_w, -1, 0, d.hidden[L - 1], 1);  // M[n][0] = W[0][n]
     // that matrix is stored as W^T[k=0][n] = M[n][0] -> contiguous over n at w_off
-    b.eltwise(G, OP_SILU_BWD_CONST, d.hidden[L - 1], zb[L - 1], dz[L - 1], -1, (int32_t)p->linears[lw].w_off);
-    for (int i = L - 1; i >= 1; --i) {
+    if (!qnet) b.eltwise(G, OP_SILU_BWD_CONST, d.hidden[L - 1], zb[L - 1], dz[L - 1], -1, (int32_t)p->linears[lw].w_off);
+    for (int i = L - 1; i >= 1 && !qnet; --i) {
       const LinearDesc li = p->linears[lin[i]];
       int lt = b.add_matrix(li.K, li.N, li.p_w, -1, 0, li.K, 1);  // W_i^T : [K_i x N_i]
       b.linear(G, lt, dz[i], ab[i - 1], -1, 0);                    // da_{i-1} (reuses the a buffer)
       b.eltwise(G, OP_SILU_BWD, d.hidden[i - 1], zb[i - 1], dz[i - 1], ab[i - 1]);
     }
     const LinearDesc l1 = p->linears[lin[0]];
-    int lx = b.add_matrix(d.x_dim, l1.N, l1.p_w, -1, d.t_dim, l1.K, 1);  // (W_1[:, x cols])^T
-    b.linear(G, lx, dz[0], p->gradx_off, -1, 0);
+    if (!qnet) {
+      int lx = b.add_matrix(d.x_dim, l1.N, l1.p_w, -1, d.t_dim, l1.K, 1);  // (W_1[:, x cols])^T
+      b.linear(G, lx, dz[0], p->gradx_off, -1, 0);
+    }
 
     // ---- training programs (CEP energy_guidance_loss, energy_conditional_diffusion_model.py:1308-1394):
     // forward keeping every pre-activation; backward from d loss / d f (tr_gout, one feature) to every
@@ -308,9 +313,9 @@ Plan* build_plan(const grlhip_net_desc& d, std::string& err) {
       p->tr_gout = t.alloc(1);
       const int hmax = *std::max_element(d.hidden, d.hidden + L);
       const int g_a = t.alloc(hmax), g_z = t.alloc(hmax);
-      p->tr_gtc = t.alloc(d.t_dim);
+      p->tr_gtc = qnet ? -1 : t.alloc(d.t_dim);
       int tin = p->tr_temb;
-      for (int i = 0; i < L; ++i) { t.linear(TF, lin[i], tin, ta[i], -1, F_SILU_OUT | F_SAVE_PRE, tz[i]); tin = ta[i]; }
+      for (int i = 0; i < L; ++i) { t.linear(TF, lin[i], tin, ta[i], -1, ACT | F_SAVE_PRE, tz[i]); tin = ta[i]; }
       t.linear(TF, lin[L], tin, p->tr_out, -1, 0);
       auto dw = [&](int li, int dzo, int ino) {
         const LinearDesc l = p->linears[li];
@@ -323,13 +328,13 @@ Plan* build_plan(const grlhip_net_desc& d, std::string& err) {
       dw(lin[L], p->tr_gout, ta[L - 1]);
       t.linear(TB, lw, p->tr_gout, g_a, -1, 0);                       // da_L = w_last * df
       for (int i = L - 1; i >= 0; --i) {
-        t.eltwise(TB, OP_SILU_BWD, d.hidden[i], tz[i], g_z, g_a);     // dz_i = da_i * silu'(z_i)
+        t.eltwise(TB, ACT_BWD, d.hidden[i], tz[i], g_z, g_a);         // dz_i = da_i * act'(z_i)
         dw(lin[i], g_z, i ? ta[i - 1] : p->tr_temb);
         const LinearDesc li = p->linears[lin[i]];
         if (i) {
           int lt = t.add_matrix(li.K, li.N, li.p_w, -1, 0, li.K, 1);  // W_i^T
           t.linear(TB, lt, g_z, g_a, -1, 0);
-        } else {
+        } else if (!qnet) {
           int lt = t.add_matrix(d.t_dim, li.N, li.p_w, -1, 0, li.K, 1);  // (W_1[:, t_emb cols])^T
           t.linear(TB, lt, g_z, p->tr_gtc, -1, 0);
         }

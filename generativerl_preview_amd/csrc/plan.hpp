@@ -23,9 +23,10 @@ enum OpType : int32_t {
   OP_SILU_BWD = 3,       // out[n] = slab[add + n] * silu'(in[n])
   OP_SILU_BWD_CONST = 4, // out[n] = wts[w + n] * silu'(in[n])
   OP_DW = 5,             // grad[w + n*pre + k] += sum_rows slab[add + n] * slab[in + k]; grad[b + n] += sum_rows slab[add + n]
-  OP_ADD = 6             // out[n] += in[n]
+  OP_ADD = 6,            // out[n] += in[n]
+  OP_RELU_BWD = 7        // out[n] = slab[add + n] * (in[n] > 0)
 };
-enum OpFlags : int32_t { F_SILU_OUT = 1, F_SAVE_PRE = 2, F_ACCUM = 4 };
+enum OpFlags : int32_t { F_SILU_OUT = 1, F_SAVE_PRE = 2, F_ACCUM = 4, F_RELU_OUT = 8 };
 
 struct Op {
   int32_t type, K, N, w, b, in, out, add, flags, pre;  // pre: where z (pre-activation) is kept (F_SAVE_PRE)

@@ -149,7 +149,7 @@ def _launch(model, t, x_t, cond, alpha, beta, target, roww, loss_rows, flat):
     B, dev = x_t.shape[0], x_t.device
     lib = L.lib()
     t, x_t, cond = _f32c(t, "t", (B,)), _f32c(x_t, "x_t", (B, plan.x_dim)), _f32c(cond, "condition")
-    alpha, beta, target = _f32c(alpha, "alpha", (B,)), _f32c(beta, "beta", (B,)), _f32c(target, "target", x_t.shape)
+    alpha, beta, target = _f32c(alpha, "alpha", (B,)), _f32c(beta, "beta", (B,)), _f32c(target, "target", (B, plan.out_dim))
     need = lib.grlhip_loss_workspace_bytes(plan.handle, B, L.F32)
     ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):

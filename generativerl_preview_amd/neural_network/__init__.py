@@ -113,6 +113,8 @@ class MultiLayerPerceptron(nn.Module):
         acts = activation if isinstance(activation, list) else [activation] * (len(hidden_sizes) - 1)
         self._fusable = (all(a.lower() in ("silu", "swish") for a in acts) and not layernorm
                          and not (dropout is not None and dropout > 0) and final_activation is None and scale is None)
+        self._relu_fusable = (all(a.lower() == "relu" for a in acts) and not layernorm
+                              and not (dropout is not None and dropout > 0) and final_activation is None and scale is None)
         self._sizes = (list(hidden_sizes), output_size)
 
     forward = _not_a_compute_path
@@ -131,6 +133,13 @@ class ConcatenateMLP(nn.Module):
                                       "dropout/layernorm/final activation/scale")
         sizes, out = self.model._sizes
         return dict(kind="concat_mlp", in_dim=sizes[0], hidden=sizes[1:], out_dim=out)
+
+    def hip_desc_qnet(self):
+        if not self.model._relu_fusable:
+            raise NotImplementedError("the fused Q-network kernels support ReLU MLPs without "
+                                      "dropout/layernorm/final activation/scale")
+        sizes, out = self.model._sizes
+        return dict(kind="qnet", in_dim=sizes[0], hidden=sizes[1:], out_dim=out)
 
     forward = _not_a_compute_path
 

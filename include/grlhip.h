@@ -34,7 +34,9 @@ typedef enum {
 
 typedef enum {
   GRLHIP_NET_RESNET = 0,    /* TemporalSpatialResidualNet, grl/neural_network/__init__.py:237-342 */
-  GRLHIP_NET_CONCAT_MLP = 1 /* ConcatenateMLP(SiLU) -> 1 output, grl/neural_network/__init__.py:558-583 */
+  GRLHIP_NET_CONCAT_MLP = 1, /* ConcatenateMLP(SiLU) -> 1 output, grl/neural_network/__init__.py:558-583 */
+  GRLHIP_NET_QNET = 2        /* QNetwork, grl/rl_modules/value_network/q_network.py:12-64: ConcatenateMLP(ReLU) over
+                                cat[action, state] -> 1, no time input (fp32 batch engine only) */
 } grlhip_net_kind;
 
 typedef enum {
@@ -48,7 +50,9 @@ typedef enum {
  * RESNET:     x_dim -> hidden[0..n_hidden) U-Net of TemporalSpatialResBlocks -> out_dim; t_dim is the
  *             width of the GaussianFourierProjectionTimeEncoder output (encoders.py:36-86);
  *             cond_dim == 0 means unconditional (then cond_hidden is ignored, t_cond_hidden = t_dim).
- * CONCAT_MLP: input cat[t_emb(t_dim), x(x_dim), c(cond_dim)] -> hidden[0..n_hidden) with SiLU -> out_dim (1). */
+ * CONCAT_MLP: input cat[t_emb(t_dim), x(x_dim), c(cond_dim)] -> hidden[0..n_hidden) with SiLU -> out_dim (1).
+ * QNET:       input cat[action(x_dim), state(cond_dim)] -> hidden[0..n_hidden) with ReLU -> out_dim (1); t_dim = 0,
+ *             the `t` argument of the entry points is ignored (may be NULL). */
 typedef struct {
   int32_t kind;
   int32_t x_dim;
@@ -185,7 +189,9 @@ int64_t grlhip_grad_offset(const grlhip_plan* plan, int index);
  * (velocity_function.py:81-218) and flow_matching_loss_icfm (:220-302).  Every variant is
  *   pred = alpha[r]*net(t[r], x_t[r], c[r]) + beta[r]*x_t[r];  loss_r = sum_d 0.5*(pred - target)^2
  * loss_rows[R] receives loss_r; grad_flat (+=) receives sum_r row_weight[r] * d loss_r / d theta
- * (row_weight NULL = 1).  grad_flat is NOT zeroed by the call. */
+ * (row_weight NULL = 1).  grad_flat is NOT zeroed by the call.
+ * QNET plans (the two regressions of QGPOCritic.q_loss, grl/algorithms/qgpo.py:132-139): x_t = action, cond = state,
+ * t and beta ignored (may be NULL), pred = alpha[r]*q(action, state), target[R,1]. */
 int grlhip_loss_fwd_bwd(const grlhip_plan* plan, const void* packed, int dtype, const float* t,
                         const float* x_t, const float* cond, const float* alpha, const float* beta,
                         const float* target, const float* row_weight, float* loss_rows,

@@ -574,3 +574,29 @@ def energy_guidance_loss(sd, path, x, cond, energy, t, noise, alpha=1.0, pre="en
     log_p = torch.log_softmax(f, dim=1)                                               # :1389
     p0 = torch.softmax(energy * alpha, dim=1)                                         # :1390
     return -torch.mean(torch.sum(p0 * log_p, dim=-1))                                 # :1391-1393
+
+
+def q_network_forward(sd, pre, action, state):
+    """QNetwork.forward, grl/rl_modules/value_network/q_network.py:48-64: ConcatenateMLP(ReLU) over cat[action, state]
+    (MultiLayerPerceptron, grl/neural_network/__init__.py:475-555)."""
+    h = torch.cat([action, state], dim=-1)
+    i = 0
+    while (pre + "model.backbone.model.model.linear%d.weight" % (i + 1)) in sd:
+        h = F.relu(_lin(sd, pre + "model.backbone.model.model.linear%d" % i, h))
+        i += 1
+    return _lin(sd, pre + "model.backbone.model.model.linear%d" % i, h)
+
+
+def q_loss(sd, action, state, reward, next_state, done, fake_next_action, q_alpha=1.0, discount_factor=1.0):
+    """QGPOCritic.q_loss, grl/algorithms/qgpo.py:85-139.  sd: the critic's state_dict ("q.model.q1...." and
+    "q_target.model.q1...."); values that require grad receive the gradient on backward."""
+    with torch.no_grad():
+        K = fake_next_action.shape[1]
+        ns = torch.stack([next_state] * K, dim=1)                                         # :118-120
+        e = torch.min(q_network_forward(sd, "q_target.model.q1.", fake_next_action, ns),
+                      q_network_forward(sd, "q_target.model.q2.", fake_next_action, ns)).squeeze(dim=-1)  # :121-128
+        next_v = torch.sum(torch.softmax(q_alpha * e, dim=1) * e, dim=-1, keepdim=True)   # :129-131
+    targets = reward + (1.0 - done.float()) * discount_factor * next_v                    # :133
+    q0 = q_network_forward(sd, "q.model.q1.", action, state)
+    q1 = q_network_forward(sd, "q.model.q2.", action, state)
+    return (F.mse_loss(q0, targets) + F.mse_loss(q1, targets)) / 2                        # :135-138
