@@ -104,6 +104,20 @@ class NetPlan:
                                                _ptr(out), rows, _ptr(ws), ws.numel(), _stream(dev)))
         return out
 
+    def backward(self, packed, t, x, cond, grad_out):
+        """grlhip_net_backward: flat parameter gradient of sum(grad_out * net(t, x, cond)) (forward recomputed)."""
+        rows = x.shape[0]
+        dev = x.device
+        t, x, cond = _f32c(t, "t", (rows,)), _f32c(x, "x", (rows, self.x_dim)), _f32c(cond, "condition")
+        grad_out = _f32c(grad_out, "grad_out", (rows, self.out_dim))
+        flat = torch.zeros(L.lib().grlhip_grad_numel(self.handle), dtype=torch.float32, device=dev)
+        need = L.lib().grlhip_loss_workspace_bytes(self.handle, rows, L.F32)
+        ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            L.check(L.lib().grlhip_net_backward(self.handle, _ptr(packed), L.F32, _ptr(t), _ptr(x), _ptr(cond),
+                                                _ptr(grad_out), _ptr(flat), rows, _ptr(ws), ws.numel(), _stream(dev)))
+        return flat
+
     def energy_grad(self, packed, t, x, cond, scale, dtype=L.F32):
         rows = x.shape[0]
         dev = x.device
@@ -165,3 +179,44 @@ class NetPlan:
                 ev[1].record(torch.cuda.current_stream(dev))
                 KERNEL_EVENTS.append(ev)
         return final, traj
+
+
+class _DifferentiableForward(torch.autograd.Function):
+    """net(t, x, cond) with a backward to the parameters (grlhip_net_backward); no gradient to t / x / cond."""
+
+    @staticmethod
+    def forward(ctx, owner, t, x, cond, *params):
+        ctx.owner = owner
+        ctx.save_for_backward(*[v for v in (t, x, cond) if v is not None])
+        ctx.has = (t is not None, cond is not None)
+        return owner.plan.forward(owner.packed(L.F32), t, x, cond, L.F32)
+
+    @staticmethod
+    def backward(ctx, gout):
+        owner = ctx.owner
+        saved = list(ctx.saved_tensors)
+        t = saved.pop(0) if ctx.has[0] else None
+        x = saved.pop(0)
+        cond = saved.pop(0) if ctx.has[1] else None
+        plan = owner.plan
+        flat = plan.backward(owner.packed(L.F32), t, x, cond, gout)
+        named = owner._named()
+        grads = []
+        for i, (name, shape) in enumerate(plan.params):
+            p = named[name]
+            if p.requires_grad:
+                off = L.lib().grlhip_grad_offset(plan.handle, i)
+                grads.append(flat[off:off + p.numel()].view(p.shape))
+            else:
+                grads.append(None)
+        return (None, None, None, None, *grads)
+
+
+def differentiable_forward(owner, t, x, cond):
+    """owner: IntrinsicModel / QNetwork (``plan``, ``packed()``, ``_named()``).  Plain forward when autograd is off or
+    no parameter requires grad; otherwise the output carries a grad_fn whose backward fills the parameters' grads."""
+    named = owner._named()
+    params = [named[n] for n, _ in owner.plan.params]
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        return _DifferentiableForward.apply(owner, t, x, cond, *params)
+    return owner.plan.forward(owner.packed(L.F32), t, x, cond, L.F32)

@@ -10,7 +10,7 @@ import torch.nn as nn
 
 from .. import _lib as L
 from ..config import as_config
-from ..engine import NetPlan
+from ..engine import NetPlan, differentiable_forward
 from ..neural_network import ConcatenateMLP, TemporalSpatialResidualNet, get_module
 from ..neural_network.encoders import GaussianFourierProjectionTimeEncoder, get_encoder
 
@@ -78,9 +78,10 @@ class IntrinsicModel(nn.Module):
 
     # ------------------------------------------------------------------ reference API
     def forward(self, t, x, condition=None):
-        """intrinsic_model.py:54-75.  Not differentiable: training goes through the fused
-        ``*_loss`` entry points."""
+        """intrinsic_model.py:54-75.  Differentiable with respect to the parameters (grlhip_net_backward recomputes
+        the forward), not with respect to t / x / condition; the ``*_loss`` methods use fused single-call kernels
+        instead."""
         if isinstance(self.model["backbone"], ConcatenateMLP) and not hasattr(self, "_io_dims"):
             self.set_io_dims(x.shape[-1], 0 if condition is None else condition.shape[-1])
         t = t.expand(x.shape[0]) if t.dim() == 0 else t
-        return self.plan.forward(self.packed(L.F32), t, x, condition, L.F32)
+        return differentiable_forward(self, t, x, condition)

@@ -1,8 +1,8 @@
 """QNetwork / DoubleQNetwork (grl/rl_modules/value_network/q_network.py:12-133): ConcatenateMLP(ReLU) critics over
 cat[action, state].  Parameters live in ordinary ``nn.Parameter``s under the reference's names
 (``model.backbone.model.model.linear0.weight`` ...); ``forward`` evaluates the network in the HIP library
-(``grlhip_net_forward`` on a QNET plan, fp32 batch engine) and is not differentiable -- training goes through
-``QGPOCritic.q_loss`` (algorithms/qgpo.py), one fused forward+backward call per critic."""
+(``grlhip_net_forward`` on a QNET plan, fp32 batch engine) and is differentiable with respect to the parameters
+(``grlhip_net_backward``); ``QGPOCritic.q_loss`` (algorithms/qgpo.py) uses one fused forward+backward call per critic."""
 import copy
 
 import torch
@@ -10,7 +10,7 @@ import torch.nn as nn
 
 from ... import _lib as L
 from ...config import as_config
-from ...engine import NetPlan
+from ...engine import NetPlan, differentiable_forward
 from ...neural_network import ConcatenateMLP, get_module
 
 
@@ -79,7 +79,7 @@ class QNetwork(nn.Module):
         lead = action.shape[:-1]
         a2 = action.reshape(-1, action.shape[-1])
         s2 = state.expand(*lead, state.shape[-1]).reshape(-1, state.shape[-1])
-        return self.plan.forward(self.packed(), None, a2, s2, L.F32).reshape(*lead, -1)
+        return differentiable_forward(self, None, a2, s2).reshape(*lead, -1)
 
 
 class DoubleQNetwork(nn.Module):

@@ -198,6 +198,16 @@ int grlhip_loss_fwd_bwd(const grlhip_plan* plan, const void* packed, int dtype, 
                         float* grad_flat, int64_t rows, void* workspace, size_t workspace_bytes,
                         void* stream);
 
+/* Replaces: torch autograd's backward through IntrinsicModel.forward / QNetwork.forward
+ * (grl/generative_models/intrinsic_model.py:54-75, grl/rl_modules/value_network/q_network.py:48-64) for losses this
+ * library has no fused kernel for (expectile / weighted regressions of the IQL critics, grl/algorithms/gmpo.py): the
+ * vector-Jacobian product grad_flat (+=) sum_r grad_out[r] . d out[r] / d theta, with the forward recomputed inside
+ * the call (nothing is kept between grlhip_net_forward and this).  No gradient with respect to x / cond / t.
+ * Workspace: grlhip_loss_workspace_bytes.  t is ignored for QNET plans. */
+int grlhip_net_backward(const grlhip_plan* plan, const void* packed, int dtype, const float* t, const float* x,
+                        const float* cond, const float* grad_out, float* grad_flat, int64_t rows,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* Replaces: the energy-guidance network's forward + autograd backward inside
  * EnergyConditionalDiffusionModel.energy_guidance_loss (contrastive energy prediction,
  * grl/generative_models/diffusion_model/energy_conditional_diffusion_model.py:1354-1394) for a CONCAT_MLP plan.
