@@ -600,3 +600,50 @@ def q_loss(sd, action, state, reward, next_state, done, fake_next_action, q_alph
     q0 = q_network_forward(sd, "q.model.q1.", action, state)
     q1 = q_network_forward(sd, "q.model.q2.", action, state)
     return (F.mse_loss(q0, targets) + F.mse_loss(q1, targets)) / 2                        # :135-138
+
+
+# ----------------------------------------------------------------------------- GMPO / IQL critic
+def v_network_forward(sd, pre, state):
+    """VNetwork.forward, grl/rl_modules/value_network/value_network.py:48-70 with a MultiLayerPerceptron(ReLU)
+    backbone (grl/neural_network/__init__.py:475-555)."""
+    h = state
+    i = 0
+    while (pre + "model.backbone.model.linear%d.weight" % (i + 1)) in sd:
+        h = F.relu(_lin(sd, pre + "model.backbone.model.linear%d" % i, h))
+        i += 1
+    return _lin(sd, pre + "model.backbone.model.linear%d" % i, h)
+
+
+def asymmetric_l2_loss(u, tau):
+    """grl/algorithms/gmpo.py:41-42"""
+    return torch.mean(torch.abs(tau - (u < 0).float()) * u ** 2)
+
+
+def _min_q(sd, pre, action, state):
+    return torch.min(q_network_forward(sd, pre + "model.q1.", action, state), q_network_forward(sd, pre + "model.q2.", action, state))
+
+
+def gmpo_v_loss(sd, state, action, next_state, tau):
+    """GMPOCritic.v_loss, grl/algorithms/gmpo.py:100-108 -> (v_loss, next_v)"""
+    with torch.no_grad():
+        target_q = _min_q(sd, "q_target.", action, state)
+        next_v = v_network_forward(sd, "v.", next_state)
+    adv = target_q - v_network_forward(sd, "v.", state)
+    return asymmetric_l2_loss(adv, tau), next_v
+
+
+def gmpo_iql_q_loss(sd, state, action, reward, done, next_v, discount):
+    """GMPOCritic.iql_q_loss, grl/algorithms/gmpo.py:110-114 -> (q_loss, mean q1, mean target)"""
+    q_target = reward + (1.0 - done.float()) * discount * next_v.detach()
+    qs = (q_network_forward(sd, "q.model.q1.", action, state), q_network_forward(sd, "q.model.q2.", action, state))
+    return sum(F.mse_loss(q, q_target) for q in qs) / len(qs), torch.mean(qs[0]), torch.mean(q_target)
+
+
+def awr_weights(sd, action, state, beta=1.0, weight_clamp=100.0):
+    """the weights of GMPOPolicy.policy_optimization_loss_by_advantage_weighted_regression,
+    grl/algorithms/gmpo.py:323-338 -> (clamped_weight, weight); critic keys "critic.q....", "critic.v...."."""
+    with torch.no_grad():
+        q_value = _min_q(sd, "critic.q.", action, state).squeeze(dim=-1)
+        v_value = v_network_forward(sd, "critic.v.", state).squeeze(dim=-1)
+        weight = torch.exp(beta * (q_value - v_value))
+    return weight.clamp(max=weight_clamp), weight
