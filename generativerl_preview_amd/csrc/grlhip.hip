@@ -394,7 +394,7 @@ int grlhip_loss_fwd_bwd(const grlhip_plan* plan, const void* packed, int dtype, 
   a.net = net_args(p, packed, false, 0);
   a.net.ops = (const Op*)p->d_train_fwd; a.net.n_ops = (int32_t)p->train_fwd.size();
   a.net.temb_off = p->tr_temb; a.net.x_off = p->tr_x; a.net.c_off = p->tr_c; a.net.out_off = p->tr_out;
-  a.bwd = (const Op*)p->d_train_bwd; a.n_bwd = (int32_t)p->train_bwd.size();
+  a.bwd = (const Op*)p->d_train_bwd; a.n_bwd = (int32_t)p->train_bwd.size() - p->train_bwd_dx_ops;
   a.gout_off = p->tr_gout; a.gtc_off = p->tr_gtc;
   a.t = t; a.x_t = x_t; a.cond = cond; a.alpha = alpha; a.beta = beta; a.target = target; a.row_weight = row_weight;
   a.loss_rows = loss_rows; a.grad = grad_flat; a.fourier_grad = 1;
@@ -445,6 +445,28 @@ int grlhip_net_backward(const grlhip_plan* plan, const void* packed, int dtype, 
   const size_t need = grlhip_loss_workspace_bytes(plan, rows, dtype);
   if (!workspace || workspace_bytes < need) return fail(GRLHIP_ERR_WORKSPACE, "workspace too small: need " + std::to_string(need));
   backward_step(p, (const float*)packed, t, x, cond, grad_out, grad_flat, rows, (float*)workspace, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int grlhip_sample_ode_backward(const grlhip_plan* plan, const void* packed, int dtype, const float* traj,
+                               const float* cond, const float* coef, int32_t n_steps, int64_t rows,
+                               const float* grad_traj, float* grad_x0, float* grad_flat, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  if (int rc = check_ready(plan, packed)) return rc;
+  const Plan* p = plan->p;
+  if (p->desc.kind != GRLHIP_NET_RESNET || p->tr_gx < 0) return fail(GRLHIP_ERR_INVALID, "sample_ode_backward needs a RESNET plan");
+  if (p->desc.out_dim != p->desc.x_dim) return fail(GRLHIP_ERR_INVALID, "sample_ode_backward needs out_dim == x_dim");
+  if (dtype != GRLHIP_F32) return fail(GRLHIP_ERR_UNSUPPORTED, "sample_ode_backward: only GRLHIP_F32 is implemented");
+  if (f32_engine_wave()) return fail(GRLHIP_ERR_UNSUPPORTED, "sample_ode_backward runs on the batch engine only (unset GRLHIP_F32_ENGINE)");
+  if (rows <= 0 || n_steps <= 0) return 0;
+  if (!traj || !coef || !grad_traj || !grad_flat) return fail(GRLHIP_ERR_INVALID, "null traj/coef/grad_traj/grad_flat");
+  if ((p->desc.cond_dim > 0) != (cond != nullptr))
+    return fail(GRLHIP_ERR_INVALID, "condition pointer does not match the plan's cond_dim");
+  const size_t need = grlhip_loss_workspace_bytes(plan, rows, dtype);
+  if (!workspace || workspace_bytes < need) return fail(GRLHIP_ERR_WORKSPACE, "workspace too small: need " + std::to_string(need));
+  OdeBwdCall c{traj, cond, coef, grad_traj, grad_x0, grad_flat, rows, n_steps};
+  ode_backward(p, (const float*)packed, c, (float*)workspace, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -244,6 +244,17 @@ Plan* build_plan(const grlhip_net_desc& d, std::string& err) {
         t.eltwise(TB, OP_SILU_BWD, ch, zc, g_zc, p->tr_gtc + d.t_dim);
         dw(b.by_name["backbone.pre_sort_condition.0"], g_zc, p->tr_c);
       }
+      // ---- input gradient (differentiable sampling only; skipped by the loss entry points): the first block's
+      // output gradient is still in gcat[0] + h[0] and its dz1 in g_z (nothing after that block writes them)
+      {
+        const Blk& k = blks[0];
+        p->tr_gx = t.alloc(d.x_dim);
+        const size_t before = TB.size();
+        if (k.lm >= 0) lin_t(k.lm, gcat[0] + h[0], p->tr_gx, false);
+        else t.eltwise(TB, OP_COPY, k.N, gcat[0] + h[0], p->tr_gx);
+        lin_t(k.l1, g_z, p->tr_gx, true);
+        p->train_bwd_dx_ops = (int32_t)(TB.size() - before);
+      }
       p->train_slab_features = up(t.bump, 2);
       b.woff = t.woff;
     }

@@ -60,6 +60,8 @@ struct Plan {
   std::vector<Op> train_fwd, train_bwd;
   int32_t train_slab_features = 0;
   int32_t tr_temb = 0, tr_x = 0, tr_c = -1, tr_out = 0, tr_gout = 0, tr_gtc = 0;
+  int32_t tr_gx = -1;            // d loss / d x (RESNET; written by the last train_bwd_dx_ops ops of train_bwd)
+  int32_t train_bwd_dx_ops = 0;  // trailing ops of train_bwd that only the differentiable integrator needs
   void* d_train_fwd = nullptr;
   void* d_train_bwd = nullptr;
   int32_t slab_features = 0;

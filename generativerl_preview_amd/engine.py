@@ -118,6 +118,22 @@ class NetPlan:
                                                 _ptr(grad_out), _ptr(flat), rows, _ptr(ws), ws.numel(), _stream(dev)))
         return flat
 
+    def sample_ode_backward(self, packed, traj, cond, coef, grad_traj):
+        """grlhip_sample_ode_backward -> (flat parameter gradient, d loss / d x0)."""
+        n1, rows, D = traj.shape
+        dev = traj.device
+        traj, grad_traj = _f32c(traj, "trajectory"), _f32c(grad_traj, "grad_traj", (n1, rows, D))
+        cond, coef = _f32c(cond, "condition"), _f32c(coef.to(dev), "coef", (n1 - 1, L.COEF_STRIDE))
+        flat = torch.zeros(L.lib().grlhip_grad_numel(self.handle), dtype=torch.float32, device=dev)
+        gx0 = torch.empty(rows, D, dtype=torch.float32, device=dev)
+        need = L.lib().grlhip_loss_workspace_bytes(self.handle, rows, L.F32)
+        ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            L.check(L.lib().grlhip_sample_ode_backward(self.handle, _ptr(packed), L.F32, _ptr(traj), _ptr(cond), _ptr(coef),
+                                                       n1 - 1, rows, _ptr(grad_traj), _ptr(gx0), _ptr(flat), _ptr(ws),
+                                                       ws.numel(), _stream(dev)))
+        return flat, gx0
+
     def energy_grad(self, packed, t, x, cond, scale, dtype=L.F32):
         rows = x.shape[0]
         dev = x.device

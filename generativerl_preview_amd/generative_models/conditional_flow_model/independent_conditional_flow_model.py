@@ -49,8 +49,6 @@ class IndependentConditionalFlowModel(nn.Module):
     def sample_forward_process(self, t_span=None, batch_size=None, x_0=None, condition=None,
                                with_grad: bool = False, solver_config=None, _final_only=False):
         """:170-450"""
-        if with_grad:
-            raise NotImplementedError("differentiable sampling (with_grad=True) is not part of the fused hot path yet")
         if t_span is not None:
             t_span = t_span.to(self.device)
         extra, n, x, condition = expand_inputs(self, batch_size, x_0, condition)
@@ -63,7 +61,7 @@ class IndependentConditionalFlowModel(nn.Module):
         if not isinstance(solver, ODESolver):
             raise NotImplementedError("Not implemented")  # :283-284,342-343
         drift = FusedDrift("icfm", self.model, self.model_type, condition=condition)
-        data = solver.integrate(drift=drift, x0=x, t_span=t_span, return_trajectory=not _final_only)
+        data = solver.integrate(drift=drift, x0=x, t_span=t_span, return_trajectory=not _final_only, with_grad=with_grad)
         if _final_only:
             data = data.unsqueeze(0)
         data = reshape_output(self, data, batch_size, extra, n, x_0, condition)

@@ -79,8 +79,6 @@ class DiffusionModel(nn.Module):
                                _final_only=False, _guidance_scale=None):
         """diffusion_model.py:135-470.  Returns (T, ...) with the reference's shape rules.
         ``noise_increments`` (superset) pins the Brownian path of the SDE solver."""
-        if with_grad:
-            raise NotImplementedError("differentiable sampling (with_grad=True) is not part of the fused hot path yet")
         if t_span is not None:
             t_span = t_span.to(self.device)
         extra, n, x, condition = expand_inputs(self, batch_size, x_0, condition)
@@ -91,6 +89,8 @@ class DiffusionModel(nn.Module):
             assert hasattr(self, "solver"), "solver must be specified in config or solver_config"
             solver = self.solver
         function, function_type = self._function(_guidance_scale)
+        if with_grad and not (isinstance(solver, ODESolver) and not isinstance(solver, DPMSolver)):
+            raise NotImplementedError("differentiable sampling (with_grad=True) is implemented for ODESolver only")
         if isinstance(solver, DPMSolver):
             # diffusion_model.py:255-279 / energy_conditional_diffusion_model.py:370-405
             assert t_span is None, "DPMSolver does not support t_span argument assignment"
@@ -102,7 +102,7 @@ class DiffusionModel(nn.Module):
         elif isinstance(solver, ODESolver):
             drift = self.diffusion_process.reverse_ode(function=function, function_type=function_type,
                                                        condition=condition).drift
-            data = solver.integrate(drift=drift, x0=x, t_span=t_span, return_trajectory=not _final_only)
+            data = solver.integrate(drift=drift, x0=x, t_span=t_span, return_trajectory=not _final_only, with_grad=with_grad)
         elif isinstance(solver, SDESolver):
             assert self.reverse_diffusion_process is not None, "reverse_path must be specified in config"
             sde = self.diffusion_process.reverse_sde(

@@ -103,10 +103,48 @@ class FusedDrift:
         return m.plan.sample(m.packed(dtype), x0, self.condition, table, dW=increments, guidance=g_plan,
                              guidance_packed=g_packed, trajectory_slots=trajectory_slots, dtype=dtype)
 
+    def integrate_with_grad(self, x0, table):
+        """Differentiable Euler chain (``with_grad=True``): the fp32 trajectory (n_steps + 1, R, D) with a grad_fn whose
+        backward walks the chain in the library (grlhip_sample_ode_backward) -- gradients reach the model's parameters
+        and x0, not the condition.  Every step of ``table`` must emit slot k + 1 with lerp 1."""
+        if self.guidance is not None:
+            raise NotImplementedError("differentiable sampling of energy-guided models is not implemented")
+        named = self.model._named()
+        params = [named[n] for n, _ in self.model.plan.params]
+        return _DifferentiableOde.apply(self, table, x0, *params)
+
     # a FusedDrift is also callable like the reference closure (one fused launch of a single step
     # evaluation is not provided; the solvers never call it)
     def __call__(self, t, x):
         raise NotImplementedError("FusedDrift is consumed whole by ODESolver/SDESolver.integrate")
+
+
+class _DifferentiableOde(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, drift, table, x0, *params):
+        m = drift.model
+        n = table.shape[0]
+        _, traj = m.plan.sample(m.packed(L.F32), x0, drift.condition, table, trajectory_slots=n + 1, dtype=L.F32)
+        ctx.drift, ctx.table = drift, table
+        ctx.save_for_backward(traj)
+        return traj
+
+    @staticmethod
+    def backward(ctx, grad_traj):
+        (traj,) = ctx.saved_tensors
+        m = ctx.drift.model
+        plan = m.plan
+        flat, gx0 = plan.sample_ode_backward(m.packed(L.F32), traj, ctx.drift.condition, ctx.table, grad_traj)
+        named = m._named()
+        grads = []
+        for i, (name, shape) in enumerate(plan.params):
+            p = named[name]
+            if p.requires_grad:
+                off = L.lib().grlhip_grad_offset(plan.handle, i)
+                grads.append(flat[off:off + p.numel()].view(p.shape))
+            else:
+                grads.append(None)
+        return (None, None, gx0 if ctx.needs_input_grad[2] else None, *grads)
 
 
 class AffineModelFn:

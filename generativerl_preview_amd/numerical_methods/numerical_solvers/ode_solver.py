@@ -17,7 +17,7 @@ class ODESolver:
         self.kwargs = kwargs
         self.library = library
 
-    def integrate(self, drift, x0, t_span, return_trajectory=True, **kwargs):
+    def integrate(self, drift, x0, t_span, return_trajectory=True, with_grad=False, **kwargs):
         self.nfe = 0
         if self.library not in ("torchdiffeq", "torchdiffeq_adjoint", "torchdyn", "torchdyn_NeuralODE"):
             raise ValueError(f"library {self.library} is not supported")
@@ -27,6 +27,10 @@ class ODESolver:
         if isinstance(drift, FusedDrift):
             ts = t_span.detach().to("cpu", torch.float32)
             table = drift.table(ts[:-1], ts[1:] - ts[:-1], torch.arange(1, n_steps + 1), torch.ones(n_steps))
+            if with_grad:
+                traj = drift.integrate_with_grad(x0, table)
+                self.nfe = n_steps
+                return traj if return_trajectory else traj[-1]
             final, traj = drift.integrate(x0, table, None, trajectory_slots=(n_steps + 1) if return_trajectory else 0)
             self.nfe = n_steps
             return traj if return_trajectory else final

@@ -208,6 +208,19 @@ int grlhip_net_backward(const grlhip_plan* plan, const void* packed, int dtype, 
                         const float* cond, const float* grad_out, float* grad_flat, int64_t rows,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* Replaces: torch autograd's backward through the Euler chain of a differentiable sample
+ * (`sample(..., with_grad=True)`: diffusion_model/diffusion_model.py:282-304,
+ * conditional_flow_model/independent_conditional_flow_model.py:285-319 -> ODESolver.integrate, used by GMPG,
+ * grl/algorithms/gmpg.py:333,517).  traj[n_steps+1][R][D] are the states a grlhip_sample_ode / _sde call with the
+ * same coef table stored (every step emitting slot k+1 with lerp 1, slot 0 = x0); grad_traj has the same shape
+ * (d loss / d traj, zeros where unused).  Walks the chain backwards, recomputing each step's forward:
+ * grad_flat (+=) d loss / d theta, grad_x0[R][D] (may be NULL) = d loss / d x0.  Unguided RESNET plans, GRLHIP_F32.
+ * Workspace: grlhip_loss_workspace_bytes. */
+int grlhip_sample_ode_backward(const grlhip_plan* plan, const void* packed, int dtype, const float* traj,
+                               const float* cond, const float* coef, int32_t n_steps, int64_t rows,
+                               const float* grad_traj, float* grad_x0, float* grad_flat,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
 /* Replaces: the energy-guidance network's forward + autograd backward inside
  * EnergyConditionalDiffusionModel.energy_guidance_loss (contrastive energy prediction,
  * grl/generative_models/diffusion_model/energy_conditional_diffusion_model.py:1354-1394) for a CONCAT_MLP plan.
