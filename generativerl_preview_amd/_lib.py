@@ -58,7 +58,7 @@ PROTOTYPES = {
     "grlhip_grad_offset": (_i64, [_vp, ctypes.c_int]),
     "grlhip_loss_fwd_bwd": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                            _i64, _vp, _sz, _vp]),
-    "grlhip_net_backward": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "grlhip_net_backward": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "grlhip_sample_ode_backward": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp,
                                                   _vp, _sz, _vp]),
     "grlhip_cep_loss_fwd_bwd": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp,

@@ -429,8 +429,8 @@ int grlhip_cep_loss_fwd_bwd(const grlhip_plan* plan, const void* packed, int dty
 }
 
 int grlhip_net_backward(const grlhip_plan* plan, const void* packed, int dtype, const float* t, const float* x,
-                        const float* cond, const float* grad_out, float* grad_flat, int64_t rows, void* workspace,
-                        size_t workspace_bytes, void* stream) {
+                        const float* cond, const float* grad_out, float* grad_flat, float* grad_x, int64_t rows,
+                        void* workspace, size_t workspace_bytes, void* stream) {
   if (int rc = check_ready(plan, packed)) return rc;
   const Plan* p = plan->p;
   if (p->train_fwd.empty()) return fail(GRLHIP_ERR_UNSUPPORTED, "net_backward: the plan has no training programs");
@@ -439,12 +439,13 @@ int grlhip_net_backward(const grlhip_plan* plan, const void* packed, int dtype, 
   if (rows <= 0) return 0;
   const bool qnet = p->desc.kind == GRLHIP_NET_QNET;
   if (qnet) t = nullptr;
-  if ((!t && !qnet) || !x || !grad_out || !grad_flat) return fail(GRLHIP_ERR_INVALID, "null t/x/grad_out/grad_flat");
+  if ((!t && !qnet) || !x || !grad_out || (!grad_flat && !grad_x)) return fail(GRLHIP_ERR_INVALID, "null t/x/grad_out, or neither grad_flat nor grad_x");
+  if (grad_x && p->tr_gx < 0) return fail(GRLHIP_ERR_UNSUPPORTED, "net_backward: this plan has no input-gradient program");
   if ((p->desc.cond_dim > 0) != (cond != nullptr))
     return fail(GRLHIP_ERR_INVALID, "condition pointer does not match the plan's cond_dim");
   const size_t need = grlhip_loss_workspace_bytes(plan, rows, dtype);
   if (!workspace || workspace_bytes < need) return fail(GRLHIP_ERR_WORKSPACE, "workspace too small: need " + std::to_string(need));
-  backward_step(p, (const float*)packed, t, x, cond, grad_out, grad_flat, rows, (float*)workspace, (hipStream_t)stream);
+  backward_step(p, (const float*)packed, t, x, cond, grad_out, grad_flat, grad_x, rows, (float*)workspace, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -350,6 +350,14 @@ Plan* build_plan(const grlhip_net_desc& d, std::string& err) {
           t.linear(TB, lt, g_z, p->tr_gtc, -1, 0);
         }
       }
+      // trailing op, run only when the caller asks for d/dx (grlhip_net_backward's grad_x): g_z still holds dz_0
+      {
+        const LinearDesc l0 = p->linears[lin[0]];
+        p->tr_gx = t.alloc(d.x_dim);
+        int lx0 = t.add_matrix(d.x_dim, l0.N, l0.p_w, -1, d.t_dim, l0.K, 1);  // (W_1[:, x cols])^T
+        t.linear(TB, lx0, g_z, p->tr_gx, -1, 0);
+        p->train_bwd_dx_ops = 1;
+      }
       p->train_slab_features = up(t.bump, 2);
       b.woff = t.woff;
     }

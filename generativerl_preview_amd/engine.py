@@ -104,19 +104,22 @@ class NetPlan:
                                                _ptr(out), rows, _ptr(ws), ws.numel(), _stream(dev)))
         return out
 
-    def backward(self, packed, t, x, cond, grad_out):
-        """grlhip_net_backward: flat parameter gradient of sum(grad_out * net(t, x, cond)) (forward recomputed)."""
+    def backward(self, packed, t, x, cond, grad_out, need_params=True, need_x=False):
+        """grlhip_net_backward: (flat parameter gradient | None, d/dx | None) of sum(grad_out * net(t, x, cond));
+        the forward is recomputed inside the call."""
         rows = x.shape[0]
         dev = x.device
         t, x, cond = _f32c(t, "t", (rows,)), _f32c(x, "x", (rows, self.x_dim)), _f32c(cond, "condition")
         grad_out = _f32c(grad_out, "grad_out", (rows, self.out_dim))
-        flat = torch.zeros(L.lib().grlhip_grad_numel(self.handle), dtype=torch.float32, device=dev)
+        flat = torch.zeros(L.lib().grlhip_grad_numel(self.handle), dtype=torch.float32, device=dev) if need_params else None
+        gx = torch.empty(rows, self.x_dim, dtype=torch.float32, device=dev) if need_x else None
         need = L.lib().grlhip_loss_workspace_bytes(self.handle, rows, L.F32)
         ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
             L.check(L.lib().grlhip_net_backward(self.handle, _ptr(packed), L.F32, _ptr(t), _ptr(x), _ptr(cond),
-                                                _ptr(grad_out), _ptr(flat), rows, _ptr(ws), ws.numel(), _stream(dev)))
-        return flat
+                                                _ptr(grad_out), _ptr(flat), _ptr(gx), rows, _ptr(ws), ws.numel(),
+                                                _stream(dev)))
+        return flat, gx
 
     def sample_ode_backward(self, packed, traj, cond, coef, grad_traj):
         """grlhip_sample_ode_backward -> (flat parameter gradient, d loss / d x0)."""
@@ -198,7 +201,7 @@ class NetPlan:
 
 
 class _DifferentiableForward(torch.autograd.Function):
-    """net(t, x, cond) with a backward to the parameters (grlhip_net_backward); no gradient to t / x / cond."""
+    """net(t, x, cond) with a backward to the parameters and to x (grlhip_net_backward); no gradient to t / cond."""
 
     @staticmethod
     def forward(ctx, owner, t, x, cond, *params):
@@ -215,24 +218,27 @@ class _DifferentiableForward(torch.autograd.Function):
         x = saved.pop(0)
         cond = saved.pop(0) if ctx.has[1] else None
         plan = owner.plan
-        flat = plan.backward(owner.packed(L.F32), t, x, cond, gout)
         named = owner._named()
+        need_params = any(ctx.needs_input_grad[4:])
+        need_x = ctx.needs_input_grad[2]
+        flat, gx = plan.backward(owner.packed(L.F32), t, x, cond, gout, need_params, need_x)
         grads = []
         for i, (name, shape) in enumerate(plan.params):
             p = named[name]
-            if p.requires_grad:
+            if p.requires_grad and flat is not None:
                 off = L.lib().grlhip_grad_offset(plan.handle, i)
                 grads.append(flat[off:off + p.numel()].view(p.shape))
             else:
                 grads.append(None)
-        return (None, None, None, None, *grads)
+        return (None, None, gx, None, *grads)
 
 
 def differentiable_forward(owner, t, x, cond):
     """owner: IntrinsicModel / QNetwork (``plan``, ``packed()``, ``_named()``).  Plain forward when autograd is off or
-    no parameter requires grad; otherwise the output carries a grad_fn whose backward fills the parameters' grads."""
+    neither x nor a parameter requires grad; otherwise the output carries a grad_fn whose backward reaches the
+    parameters and x (for a Q network: the action)."""
     named = owner._named()
     params = [named[n] for n, _ in owner.plan.params]
-    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
         return _DifferentiableForward.apply(owner, t, x, cond, *params)
     return owner.plan.forward(owner.packed(L.F32), t, x, cond, L.F32)

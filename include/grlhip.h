@@ -201,11 +201,13 @@ int grlhip_loss_fwd_bwd(const grlhip_plan* plan, const void* packed, int dtype, 
 /* Replaces: torch autograd's backward through IntrinsicModel.forward / QNetwork.forward
  * (grl/generative_models/intrinsic_model.py:54-75, grl/rl_modules/value_network/q_network.py:48-64) for losses this
  * library has no fused kernel for (expectile / weighted regressions of the IQL critics, grl/algorithms/gmpo.py): the
- * vector-Jacobian product grad_flat (+=) sum_r grad_out[r] . d out[r] / d theta, with the forward recomputed inside
- * the call (nothing is kept between grlhip_net_forward and this).  No gradient with respect to x / cond / t.
+ * vector-Jacobian products grad_flat (+=) sum_r grad_out[r] . d out[r] / d theta (NULL: skipped) and
+ * grad_x[R,x_dim] = grad_out[r] . d out[r] / d x[r] (NULL: skipped; for a QNET plan x is the action -- the path of the
+ * GMPG policy gradient, grl/algorithms/gmpg.py:517-534), with the forward recomputed inside the call (nothing is kept
+ * between grlhip_net_forward and this).  No gradient with respect to cond / t.
  * Workspace: grlhip_loss_workspace_bytes.  t is ignored for QNET plans. */
 int grlhip_net_backward(const grlhip_plan* plan, const void* packed, int dtype, const float* t, const float* x,
-                        const float* cond, const float* grad_out, float* grad_flat, int64_t rows,
+                        const float* cond, const float* grad_out, float* grad_flat, float* grad_x, int64_t rows,
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* Replaces: torch autograd's backward through the Euler chain of a differentiable sample

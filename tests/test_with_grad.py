@@ -70,3 +70,41 @@ def test_gpu_with_grad_limits():
     kind, cfg, m = um.build("small_vp_noise", DEV)
     with pytest.raises(NotImplementedError):   # DPM-Solver / SDE solvers: ODESolver only
         m.sample(x_0=x0, condition=c, with_grad=True, solver_config=dict(type="DPMSolver", args=dict(order=2, device=DEV, steps=5)))
+
+
+@pytest.mark.gpu
+def test_gpu_policy_gradient_through_sample_and_critic():
+    """The GMPG objective (grl/algorithms/gmpg.py:517-534): actions sampled with grad from the flow policy, scored by
+    the double-Q critic, loss = -mean(min Q).  The gradient runs back through the critic's input gradient
+    (grlhip_net_backward grad_x) and the Euler chain (grlhip_sample_ode_backward) into the policy's parameters."""
+    from generativerl_preview_amd.rl_modules.value_network import DoubleQNetwork
+    name = "small_icfm"
+    kind, cfg, m = um.build(name, DEV)
+    g = gu.load("iql.npz")
+    pre = "halfcheetah/w/q."
+    qsd = {k[len(pre):]: torch.from_numpy(v) for k, v in g.items() if k.startswith(pre)}
+    q = DoubleQNetwork(dict(backbone=dict(type="ConcatenateMLP", args=dict(hidden_sizes=[23, 256, 256], output_size=1,
+                                                                          activation="relu")))).to(DEV)
+    q.load_state_dict(qsd)
+    gen = torch.Generator().manual_seed(13)
+    rows, steps = 500, 8
+    x0, state = torch.randn(rows, 6, generator=gen), torch.randn(rows, 17, generator=gen)
+    t_span = torch.linspace(0, 1, steps + 1)
+    a = m.sample(t_span=t_span.to(DEV), x_0=x0.to(DEV), condition=state.to(DEV), with_grad=True)
+    loss = -q(a, state.to(DEV)).mean()
+    loss.backward()
+    sd = {k: (v.clone().requires_grad_(True) if k.startswith("model.") and not k.endswith("t_encoder.W") else v)
+          for k, v in gu.weights(name).items()}
+    osd = {"q." + k: v.clone().requires_grad_(True) for k, v in qsd.items()}
+    ref_a = O.sample_forward_process(sd, cfg, kind, t_span, x_0=x0, condition=state)[-1]
+    want = -torch.min(O.q_network_forward(osd, "q.model.q1.", ref_a, state), O.q_network_forward(osd, "q.model.q2.", ref_a, state)).mean()
+    keys = [k for k, v in sd.items() if v.requires_grad]
+    qkeys = list(osd)
+    grads = torch.autograd.grad(want, [sd[k] for k in keys] + [osd[k] for k in qkeys])
+    rel_close(loss, want.detach(), 2e-5, "objective")
+    named = dict(m.named_parameters())
+    for k, gr in zip(keys, grads[:len(keys)]):
+        rel_close(named[k].grad, gr, 2e-3, k)
+    qnamed = dict(q.named_parameters())
+    for k, gr in zip(qkeys, grads[len(keys):]):
+        rel_close(qnamed[k[2:]].grad, gr, 2e-3, k)
