@@ -169,7 +169,7 @@ class NetPlan:
 
     def sample(self, packed, x0, cond, coef, dW=None, guidance=None, guidance_packed=None, trajectory_slots=0,
                dtype=L.F32):
-        """coef: (n_steps, 8) fp32 table (see include/grlhip.h).  Returns (final, traj|None)."""
+        """coef: (n_steps, COEF_STRIDE) fp32 table (see include/grlhip.h).  Returns (final, traj|None)."""
         rows, D = x0.shape
         dev = x0.device
         x0, cond = _f32c(x0, "x_0", (rows, self.x_dim)), _f32c(cond, "condition")

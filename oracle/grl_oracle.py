@@ -589,7 +589,9 @@ def q_network_forward(sd, pre, action, state):
 
 def q_loss(sd, action, state, reward, next_state, done, fake_next_action, q_alpha=1.0, discount_factor=1.0):
     """QGPOCritic.q_loss, grl/algorithms/qgpo.py:85-139.  sd: the critic's state_dict ("q.model.q1...." and
-    "q_target.model.q1...."); values that require grad receive the gradient on backward."""
+    "q_target.model.q1...."); values that require grad receive the gradient on backward.
+    PARITY UNPINNED for this composition (grl/algorithms/qgpo.py cannot be imported here: torchrl, gym, d4rl are
+    absent); the networks it calls are pinned by tests/golden/qloss.npz, made with the reference's DoubleQNetwork."""
     with torch.no_grad():
         K = fake_next_action.shape[1]
         ns = torch.stack([next_state] * K, dim=1)                                         # :118-120
@@ -624,7 +626,8 @@ def _min_q(sd, pre, action, state):
 
 
 def gmpo_v_loss(sd, state, action, next_state, tau):
-    """GMPOCritic.v_loss, grl/algorithms/gmpo.py:100-108 -> (v_loss, next_v)"""
+    """GMPOCritic.v_loss, grl/algorithms/gmpo.py:100-108 -> (v_loss, next_v).  PARITY UNPINNED for the composition
+    (gmpo.py cannot be imported here); networks pinned by tests/golden/iql.npz (reference DoubleQNetwork / VNetwork)."""
     with torch.no_grad():
         target_q = _min_q(sd, "q_target.", action, state)
         next_v = v_network_forward(sd, "v.", next_state)
@@ -633,7 +636,8 @@ def gmpo_v_loss(sd, state, action, next_state, tau):
 
 
 def gmpo_iql_q_loss(sd, state, action, reward, done, next_v, discount):
-    """GMPOCritic.iql_q_loss, grl/algorithms/gmpo.py:110-114 -> (q_loss, mean q1, mean target)"""
+    """GMPOCritic.iql_q_loss, grl/algorithms/gmpo.py:110-114 -> (q_loss, mean q1, mean target).  PARITY UNPINNED for
+    the composition, as gmpo_v_loss."""
     q_target = reward + (1.0 - done.float()) * discount * next_v.detach()
     qs = (q_network_forward(sd, "q.model.q1.", action, state), q_network_forward(sd, "q.model.q2.", action, state))
     return sum(F.mse_loss(q, q_target) for q in qs) / len(qs), torch.mean(qs[0]), torch.mean(q_target)
@@ -641,7 +645,8 @@ def gmpo_iql_q_loss(sd, state, action, reward, done, next_v, discount):
 
 def awr_weights(sd, action, state, beta=1.0, weight_clamp=100.0):
     """the weights of GMPOPolicy.policy_optimization_loss_by_advantage_weighted_regression,
-    grl/algorithms/gmpo.py:323-338 -> (clamped_weight, weight); critic keys "critic.q....", "critic.v...."."""
+    grl/algorithms/gmpo.py:323-338 -> (clamped_weight, weight); critic keys "critic.q....", "critic.v....".
+    PARITY UNPINNED (no reference output available for it here)."""
     with torch.no_grad():
         q_value = _min_q(sd, "critic.q.", action, state).squeeze(dim=-1)
         v_value = v_network_forward(sd, "critic.v.", state).squeeze(dim=-1)
