@@ -155,7 +155,7 @@ class DPMSolver:
         orders = self.get_orders_for_singlestep_solver(steps=steps, order=self.order)
         ts = self.get_time_steps(t_T=t_T, t_0=t_0, N=steps)
         fn = data_prediction_function if plus else noise_function
-        if self.fused and hasattr(fn, "coefficients") and max(orders) <= 2 and x.is_cuda and x.dim() == 2:
+        if self.fused and hasattr(fn, "coefficients") and (max(orders) <= 2 or high) and x.is_cuda and x.dim() == 2:
             return self._integrate_fused(dp, fn, x, condition, orders, ts, save_intermediate)
         x_list = [x.clone()] if save_intermediate else None
         with torch.no_grad():
@@ -172,8 +172,10 @@ class DPMSolver:
         return torch.stack(x_list, dim=0) if save_intermediate else x
 
     def _integrate_fused(self, dp, fn, x, condition, orders, ts, save_intermediate):
-        """Orders 1-2: every stage is `m = cn net + cx x + cg dE/dx; x <- P x + Q xs + R m + W ms` (include/grlhip.h,
-        grlhip_sample_stages); the same scalars as the host-driven path, tabulated once."""
+        """Orders 1-2, and order 3 with solver_type "dpm_solver" (its last stage needs only the first model value; the
+        "taylor" form also needs the second and stays host-driven): every stage is
+        `m = cn net + cx x + cg dE/dx; x <- P x + Q xs + R m + W ms` (include/grlhip.h, grlhip_sample_stages); the same
+        scalars as the host-driven path, tabulated once."""
         from ... import _lib as L
         plus, high = self.use_dpm_solver_plus_plus, self.default_high_order_solvers
         lam, la, sig = dp.HalfLogSNR, dp.log_scale, dp.std
@@ -192,6 +194,25 @@ class DPMSolver:
             lead = (torch.exp(la(t)) * torch.expm1(-h)) if plus else (sig(t) * torch.expm1(h))  # coefficient of m_s
             if o == 1:
                 stage(s, keep, 0.0, -lead, 0.0, 0, emit)
+            elif o == 3:
+                r1, r2 = (lam(ts[i + 1]) - lam(s)) / h, (lam(ts[i + 2]) - lam(s)) / h
+                s1 = dp.InverseHalfLogSNR(lam(s) + r1 * h).reshape(-1)[0]
+                s2 = dp.InverseHalfLogSNR(lam(s) + r2 * h).reshape(-1)[0]
+                if plus:
+                    a2, at = torch.exp(la(s2)), torch.exp(la(t))
+                    p12, p1 = torch.expm1(-r2 * h), torch.expm1(-h)
+                    c2 = r2 / r1 * a2 * (p12 / (r2 * h) + 1.0)            # x2 = .. + c2 (m1 - m)
+                    c3 = (1.0 / r2) * at * (p1 / h + 1.0)                  # x_t = .. + c3 (m2 - m)
+                    stage(s, sig(s1) / sig(s), 0.0, -(torch.exp(la(s1)) * torch.expm1(-r1 * h)), 0.0, 1, -1)
+                    stage(s1, 0.0, sig(s2) / sig(s), c2, -(a2 * p12) - c2, 0, -1)
+                    stage(s2, 0.0, keep, c3, -lead - c3, 0, emit)
+                else:
+                    p12, p1 = torch.expm1(r2 * h), torch.expm1(h)
+                    c2 = r2 / r1 * sig(s2) * (p12 / (r2 * h) - 1.0)        # x2 = .. - c2 (m1 - m)
+                    c3 = (1.0 / r2) * sig(t) * (p1 / h - 1.0)              # x_t = .. - c3 (m2 - m)
+                    stage(s, torch.exp(la(s1) - la(s)), 0.0, -(sig(s1) * torch.expm1(r1 * h)), 0.0, 1, -1)
+                    stage(s1, 0.0, torch.exp(la(s2) - la(s)), -c2, -(sig(s2) * p12) + c2, 0, -1)
+                    stage(s2, 0.0, keep, -c3, -lead + c3, 0, emit)
             else:
                 r1 = (lam(ts[i + 1]) - lam(s)) / h
                 s1 = dp.InverseHalfLogSNR(lam(s) + r1 * h).reshape(-1)[0]

@@ -158,7 +158,7 @@ int grlhip_sample_sde(const grlhip_plan* plan, const void* packed, int dtype,
                       int32_t n_steps, int64_t rows, float* out_final, float* out_traj,
                       void* workspace, size_t workspace_bytes, void* stream);
 
-/* Replaces: DPMSolver.integrate, method "singlestep", orders 1-2
+/* Replaces: DPMSolver.integrate, method "singlestep", orders 1-2 and order 3 with solver_type "dpm_solver"
  * (grl/numerical_methods/numerical_solvers/dpm_solver.py:250-391,854-904) and any other solver whose step is a
  * sequence of STAGES, each one evaluation of the network (and energy gradient) followed by an affine update with
  * one saved state and one saved model output.  stage_table[n_stages][GRLHIP_COEF_STRIDE], a HOST-computed DEVICE

@@ -140,8 +140,8 @@ def test_gpu_fused_stages_equal_host_driven_stages_and_bf16_runs_in_the_persiste
     orig = engine.NetPlan.sample_stages
     engine.NetPlan.sample_stages = lambda self, *a, **k: (calls.append(k.get("dtype")), orig(self, *a, **k))[1]
     try:
-        for typ in ("dpm_solver++", "dpm_solver"):
-            args = dict(order=2, device=DEV, steps=17, type=typ)
+        for typ, order in (("dpm_solver++", 2), ("dpm_solver", 2), ("dpm_solver++", 3), ("dpm_solver", 3)):
+            args = dict(order=order, device=DEV, steps=17, type=typ)
             fused = m.sample_forward_process(x_0=x0.to(DEV), condition=cond.to(DEV), guidance_scale=1.0,
                                              solver_config=dict(type="DPMSolver", args=args))
             assert len(calls) >= 1
@@ -150,7 +150,11 @@ def test_gpu_fused_stages_equal_host_driven_stages_and_bf16_runs_in_the_persiste
             nf, df = m._dpm_functions(1.0)
             host = solver.integrate(m.diffusion_process, nf, df, x0.to(DEV), cond.to(DEV), save_intermediate=True)
             assert solver.nfe == 17
-            close(fused.cpu(), host.cpu(), 2e-5, "fused vs host-driven " + typ)
+            close(fused.cpu(), host.cpu(), 2e-5, "fused vs host-driven %s order %d" % (typ, order))
+        n_fused = len(calls)
+        m.sample_forward_process(x_0=x0.to(DEV), condition=cond.to(DEV), guidance_scale=1.0, solver_config=dict(
+            type="DPMSolver", args=dict(order=3, device=DEV, steps=9, type="dpm_solver", solver_type="taylor")))
+        assert len(calls) == n_fused   # the taylor form of order 3 needs two saved model values: host-driven
         # bf16: the persistent integrator; dpm_solver++ keeps the states O(1)
         path, mt = O.Path(cfg["path"]), cfg["model"]["type"]
         score = lambda t, x: O.guided_score(sd, mt, path, t, x, cond, 1.0)  # noqa: E731
