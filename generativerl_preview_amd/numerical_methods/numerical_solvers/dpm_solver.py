@@ -172,11 +172,24 @@ class DPMSolver:
         return torch.stack(x_list, dim=0) if save_intermediate else x
 
     def _integrate_fused(self, dp, fn, x, condition, orders, ts, save_intermediate):
+        from ... import _lib as L
+        table = self.stage_table(dp, fn, orders, ts, save_intermediate)
+        assert table.shape[1] == L.COEF_STRIDE
+        self.nfe += table.shape[0]
+        m = fn.model
+        dtype = m.compute_dtype
+        g_plan = g_packed = None
+        if fn.guidance is not None:
+            g_plan, g_packed = fn.guidance.plan, fn.guidance.packed(dtype)
+        final, traj = m.plan.sample_stages(m.packed(dtype), x, condition, table, guidance=g_plan, guidance_packed=g_packed,
+                                           trajectory_slots=len(orders) + 1 if save_intermediate else 0, dtype=dtype)
+        return traj if save_intermediate else final
+
+    def stage_table(self, dp, fn, orders, ts, save_intermediate=True):
         """Orders 1-2, and order 3 with solver_type "dpm_solver" (its last stage needs only the first model value; the
         "taylor" form also needs the second and stays host-driven): every stage is
         `m = cn net + cx x + cg dE/dx; x <- P x + Q xs + R m + W ms` (include/grlhip.h, grlhip_sample_stages); the same
         scalars as the host-driven path, tabulated once."""
-        from ... import _lib as L
         plus, high = self.use_dpm_solver_plus_plus, self.default_high_order_solvers
         lam, la, sig = dp.HalfLogSNR, dp.log_scale, dp.std
         rows = []
@@ -232,14 +245,4 @@ class DPMSolver:
                         c = (1.0 / r1) * sig(t) * ((torch.exp(h) - 1.0) / h - 1.0)
                     stage(s1, 0.0, keep, -c, -lead + c, 0, emit)
             i += o
-        self.nfe += len(rows)
-        table = torch.tensor(rows, dtype=torch.float32)
-        assert table.shape[1] == L.COEF_STRIDE
-        m = fn.model
-        dtype = m.compute_dtype
-        g_plan = g_packed = None
-        if fn.guidance is not None:
-            g_plan, g_packed = fn.guidance.plan, fn.guidance.packed(dtype)
-        final, traj = m.plan.sample_stages(m.packed(dtype), x, condition, table, guidance=g_plan, guidance_packed=g_packed,
-                                           trajectory_slots=len(orders) + 1 if save_intermediate else 0, dtype=dtype)
-        return traj if save_intermediate else final
+        return torch.tensor(rows, dtype=torch.float32)

@@ -173,3 +173,50 @@ def test_gpu_fused_stages_equal_host_driven_stages_and_bf16_runs_in_the_persiste
               want[-1].detach(), 2e-2, "bf16 fused DPM-Solver++ final")
     finally:
         engine.NetPlan.sample_stages = orig
+
+
+@pytest.mark.parametrize("name,typ,order,steps", [("small_vp_noise", "dpm_solver", 2, 17), ("small_vp_velocity", "dpm_solver++", 2, 10),
+                                                  ("small_energy", "dpm_solver", 3, 10), ("small_energy", "dpm_solver++", 3, 9),
+                                                  ("small_vp_score", "dpm_solver++", 1, 6)])
+def test_stage_table_reproduces_the_solver_on_the_cpu(name, typ, order, steps):
+    """Host logic of the fused path, no GPU: the stage table DPMSolver hands to grlhip_sample_stages, executed by a
+    ten-line interpreter over the ORACLE's network (and energy gradient), gives the oracle's DPM-Solver trajectory."""
+    from generativerl_preview_amd.numerical_methods.numerical_solvers import DPMSolver
+    kind, cfg, m = um.build(name)
+    sd = gu.weights(name)
+    gen = torch.Generator().manual_seed(2)
+    x0, cond = torch.randn(9, 6, generator=gen), torch.randn(9, 17, generator=gen)
+    solver = DPMSolver(order=order, device="cpu", steps=steps, type=typ)
+    gs = 1.0 if kind == "energy" else None
+    noise_fn, data_fn = m._dpm_functions(gs)
+    fn = data_fn if typ == "dpm_solver++" else noise_fn
+    orders = solver.get_orders_for_singlestep_solver(steps=steps, order=order)
+    ts = solver.get_time_steps(t_T=float(m.diffusion_process.t_max), t_0=0.00001, N=steps)
+    table = solver.stage_table(m.diffusion_process, fn, orders, ts)
+    assert table.shape == (steps, 12) and int(table[:, 9].max()) == len(orders)
+    x, xs, ms, traj = x0, torch.zeros_like(x0), torch.zeros_like(x0), [x0]
+    for row in table.tolist():
+        tau, P, Q, R, W, cn, cx, cg, save, emit = row[:10]
+        t = torch.full((x.shape[0],), tau)
+        mval = cn * O.intrinsic_forward(sd, t, x, cond) + cx * x
+        if kind == "energy":
+            mval = mval + cg * O.energy_guidance(sd, t, x, cond, 1.0)
+        xn = P * x + Q * xs + R * mval + W * ms
+        if save:
+            xs, ms = x, mval
+        x = xn
+        if emit >= 0:
+            traj.append(x)
+    path, mt = O.Path(cfg["path"]), cfg["model"]["type"]
+    if kind == "energy":
+        score = lambda t, y: O.guided_score(sd, mt, path, t, y, cond, 1.0)  # noqa: E731
+        nf = lambda t, y: -score(t, y) * O._b(path.std(t), y)  # noqa: E731
+        df = lambda t, y: (-O._b(path.std(t), y) * y + O._b(path.cov(t), y) * score(t, y)) / O._b(path.scale(t), y)  # noqa: E731
+    else:
+        net = lambda t, y: O.intrinsic_forward(sd, t, y, cond)  # noqa: E731
+        nf = lambda t, y: O.noise_head(mt, path, net(t, y), t, y)  # noqa: E731
+        df = lambda t, y: O.data_head(mt, path, net(t, y), t, y)  # noqa: E731
+    want = O.dpm_solver_integrate(path, nf, df, x0, steps=steps, order=order, type=typ)
+    got = torch.stack(traj)
+    assert got.shape == want.shape
+    close(got.detach(), want.detach(), 2e-4, "stage table vs oracle solver")
