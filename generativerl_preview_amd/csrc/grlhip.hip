@@ -25,7 +25,7 @@ int device_cus() {
 }
 }  // namespace grlhip
 
-#include "engine_f32.hip.inc"
+#include "pack_f32.hip.inc"
 #include "engine_batch.hip.inc"
 #include "engine_bf16_host.hip.inc"
 
@@ -46,36 +46,6 @@ int fail(int code, const std::string& msg) {
     hipError_t e_ = (expr);                                                                    \
     if (e_ != hipSuccess) return fail(GRLHIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
-
-// fp32 engine launch geometry: 4 waves (=4 row tiles in flight) per block, <= 4 blocks per CU
-int f32_blocks(int64_t rows) {
-  const int64_t ntiles = (rows + 31) / 32;
-  const int64_t want = (ntiles + 3) / 4;
-  const int64_t cap = (int64_t)device_cus() * 4;
-  return (int)std::max<int64_t>(1, std::min(want, cap));
-}
-
-NetArgs net_args(const Plan* p, const void* packed, bool grad_program, int slab_base) {
-  NetArgs n{};
-  n.w = (const float*)packed;
-  n.ops = (const Op*)(grad_program ? p->d_grad : p->d_fwd);
-  n.n_ops = (int32_t)(grad_program ? p->grad.size() : p->fwd.size());
-  n.temb_off = p->temb_off; n.x_off = p->x_off; n.c_off = p->c_off;
-  n.out_off = grad_program ? p->gradx_off : p->out_off;
-  n.t_dim = p->desc.t_dim; n.x_dim = p->desc.x_dim; n.c_dim = p->desc.cond_dim;
-  n.out_dim = grad_program ? p->desc.x_dim : p->desc.out_dim;
-  n.fourier_off = (int32_t)p->fourier_off;
-  n.slab_base = slab_base;
-  return n;
-}
-
-// GRLHIP_F32_ENGINE=wave selects the per-wave interpreter kernels (engine_f32.hip.inc: one launch per
-// call, activations in per-wave slabs) instead of the whole-batch layer-by-layer engine
-// (engine_batch.hip.inc) for every GRLHIP_F32 entry point; kept for A/B measurements.
-bool f32_engine_wave() {
-  static const bool wave = [] { const char* e = std::getenv("GRLHIP_F32_ENGINE"); return e && std::string(e) == "wave"; }();
-  return wave;
-}
 
 int upload(const std::vector<Op>& ops, void** d) {
   *d = nullptr;
@@ -211,9 +181,7 @@ size_t grlhip_workspace_bytes(const grlhip_plan* plan, const grlhip_plan* guidan
     if (bf16_fused_ok(plan->p)) return bf16_workspace_bytes(plan->p, guidance ? guidance->p : nullptr, rows);
     return batch_workspace_bytes(plan->p, guidance ? guidance->p : nullptr, rows);
   }
-  if (!f32_engine_wave()) return batch_workspace_bytes(plan->p, guidance ? guidance->p : nullptr, rows);
-  const int64_t feats = plan->p->slab_features + (guidance && guidance->p ? guidance->p->slab_features : 0);
-  return (size_t)f32_blocks(rows) * 4 * feats * 32 * sizeof(float);
+  return batch_workspace_bytes(plan->p, guidance ? guidance->p : nullptr, rows);
 }
 
 int grlhip_net_forward(const grlhip_plan* plan, const void* packed, int dtype, const float* t, const float* x,
@@ -224,24 +192,13 @@ int grlhip_net_forward(const grlhip_plan* plan, const void* packed, int dtype, c
   if (rows <= 0) return 0;
   const bool qnet = p->desc.kind == GRLHIP_NET_QNET;
   if ((!t && !qnet) || !x || !out) return fail(GRLHIP_ERR_INVALID, "null t/x/out");
-  if (qnet && f32_engine_wave()) return fail(GRLHIP_ERR_UNSUPPORTED, "QNET plans run on the batch engine only (unset GRLHIP_F32_ENGINE)");
   if ((p->desc.cond_dim > 0) != (cond != nullptr))
     return fail(GRLHIP_ERR_INVALID, "condition pointer does not match the plan's cond_dim");
   if (dtype != GRLHIP_F32) return fail(GRLHIP_ERR_UNSUPPORTED, "net_forward: only GRLHIP_F32 is implemented");
   const size_t need = grlhip_workspace_bytes(plan, nullptr, rows, dtype);
   if (!workspace || workspace_bytes < need) return fail(GRLHIP_ERR_WORKSPACE, "workspace too small: need " + std::to_string(need));
   hipStream_t st = (hipStream_t)stream;
-  if (!f32_engine_wave()) {
-    batch_forward(p, (const float*)packed, t, x, cond, out, rows, 0, 1.0f, (float*)workspace, st);
-    HIP_TRY(hipGetLastError());
-    return 0;
-  }
-  HIP_TRY(hipMemsetAsync(workspace, 0, need, st));
-  ForwardArgs a{};
-  a.net = net_args(p, packed, false, 0);
-  a.t = t; a.x = x; a.cond = cond; a.out = out; a.rows = rows; a.workspace = (float*)workspace;
-  a.slab_features = p->slab_features; a.mode = 0; a.scale = 1.f;
-  hipLaunchKernelGGL(k_forward_f32, dim3(f32_blocks(rows)), dim3(256), 0, st, a);
+  batch_forward(p, (const float*)packed, t, x, cond, out, rows, 0, 1.0f, (float*)workspace, st);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -260,17 +217,7 @@ int grlhip_energy_grad(const grlhip_plan* plan, const void* packed, int dtype, c
   const size_t need = grlhip_workspace_bytes(plan, nullptr, rows, dtype);
   if (!workspace || workspace_bytes < need) return fail(GRLHIP_ERR_WORKSPACE, "workspace too small: need " + std::to_string(need));
   hipStream_t st = (hipStream_t)stream;
-  if (!f32_engine_wave()) {
-    batch_forward(p, (const float*)packed, t, x, cond, grad, rows, 1, scale, (float*)workspace, st);
-    HIP_TRY(hipGetLastError());
-    return 0;
-  }
-  HIP_TRY(hipMemsetAsync(workspace, 0, need, st));
-  ForwardArgs a{};
-  a.net = net_args(p, packed, true, 0);
-  a.t = t; a.x = x; a.cond = cond; a.out = grad; a.rows = rows; a.workspace = (float*)workspace;
-  a.slab_features = p->slab_features; a.mode = 1; a.scale = scale;
-  hipLaunchKernelGGL(k_forward_f32, dim3(f32_blocks(rows)), dim3(256), 0, st, a);
+  batch_forward(p, (const float*)packed, t, x, cond, grad, rows, 1, scale, (float*)workspace, st);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -313,21 +260,8 @@ static int sample_common(const grlhip_plan* plan, const void* packed, int dtype,
   if (dtype != GRLHIP_F32) return fail(GRLHIP_ERR_UNSUPPORTED, "unknown dtype");
   const size_t need = grlhip_workspace_bytes(plan, guidance, rows, dtype);
   if (!workspace || workspace_bytes < need) return fail(GRLHIP_ERR_WORKSPACE, "workspace too small: need " + std::to_string(need));
-  if (!f32_engine_wave()) {
-    SampleCall c{x0, cond, coef, dW, out_final, out_traj, rows, n_steps};
-    batch_sample(p, (const float*)packed, g, (const float*)guidance_packed, c, (float*)workspace, st, false, stages);
-    HIP_TRY(hipGetLastError());
-    return 0;
-  }
-  if (stages) return fail(GRLHIP_ERR_UNSUPPORTED, "sample_stages is not available on the per-wave engine (GRLHIP_F32_ENGINE=wave)");
-  HIP_TRY(hipMemsetAsync(workspace, 0, need, st));
-  SampleArgs a{};
-  a.net = net_args(p, packed, false, 0);
-  if (g) a.gnet = net_args(g, guidance_packed, true, p->slab_features);
-  a.x0 = x0; a.cond = cond; a.coef = coef; a.dW = dW; a.out_final = out_final; a.out_traj = out_traj;
-  a.rows = rows; a.n_steps = n_steps; a.slab_features = p->slab_features + (g ? g->slab_features : 0);
-  a.workspace = (float*)workspace;
-  hipLaunchKernelGGL(k_sample_f32, dim3(f32_blocks(rows)), dim3(256), 0, st, a);
+  SampleCall c{x0, cond, coef, dW, out_final, out_traj, rows, n_steps};
+  batch_sample(p, (const float*)packed, g, (const float*)guidance_packed, c, (float*)workspace, st, false, stages);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -359,8 +293,7 @@ int grlhip_sample_stages(const grlhip_plan* plan, const void* packed, int dtype,
 
 size_t grlhip_loss_workspace_bytes(const grlhip_plan* plan, int64_t rows, int dtype) {
   if (!plan || !plan->p || rows <= 0 || dtype != GRLHIP_F32 || plan->p->train_fwd.empty()) return 0;
-  if (!f32_engine_wave()) return train_workspace_bytes(plan->p, rows);
-  return (size_t)f32_blocks(rows) * 4 * plan->p->train_slab_features * 32 * sizeof(float);
+  return train_workspace_bytes(plan->p, rows);
 }
 
 int grlhip_loss_fwd_bwd(const grlhip_plan* plan, const void* packed, int dtype, const float* t, const float* x_t,
@@ -374,7 +307,6 @@ int grlhip_loss_fwd_bwd(const grlhip_plan* plan, const void* packed, int dtype, 
     return fail(GRLHIP_ERR_UNSUPPORTED, "loss_fwd_bwd needs a RESNET or QNET plan");
   if (!qnet && p->desc.out_dim != p->desc.x_dim) return fail(GRLHIP_ERR_INVALID, "loss_fwd_bwd needs out_dim == x_dim");
   if (dtype != GRLHIP_F32) return fail(GRLHIP_ERR_UNSUPPORTED, "loss_fwd_bwd: only GRLHIP_F32 is implemented");
-  if (qnet && f32_engine_wave()) return fail(GRLHIP_ERR_UNSUPPORTED, "QNET plans run on the batch engine only (unset GRLHIP_F32_ENGINE)");
   if (rows <= 0) return 0;
   if (qnet) { t = nullptr; beta = nullptr; }
   if ((!t && !qnet) || !x_t || !alpha || (!beta && !qnet) || !target || !loss_rows) return fail(GRLHIP_ERR_INVALID, "null t/x_t/alpha/beta/target/loss_rows");
@@ -383,23 +315,8 @@ int grlhip_loss_fwd_bwd(const grlhip_plan* plan, const void* packed, int dtype, 
   const size_t need = grlhip_loss_workspace_bytes(plan, rows, dtype);
   if (!workspace || workspace_bytes < need) return fail(GRLHIP_ERR_WORKSPACE, "workspace too small: need " + std::to_string(need));
   hipStream_t st = (hipStream_t)stream;
-  if (!f32_engine_wave()) {
-    TrainCall c{t, x_t, cond, alpha, beta, target, row_weight, loss_rows, grad_flat, rows};
-    train_step(p, (const float*)packed, c, (float*)workspace, st);
-    HIP_TRY(hipGetLastError());
-    return 0;
-  }
-  HIP_TRY(hipMemsetAsync(workspace, 0, need, st));
-  LossArgs a{};
-  a.net = net_args(p, packed, false, 0);
-  a.net.ops = (const Op*)p->d_train_fwd; a.net.n_ops = (int32_t)p->train_fwd.size();
-  a.net.temb_off = p->tr_temb; a.net.x_off = p->tr_x; a.net.c_off = p->tr_c; a.net.out_off = p->tr_out;
-  a.bwd = (const Op*)p->d_train_bwd; a.n_bwd = (int32_t)p->train_bwd.size() - p->train_bwd_dx_ops;
-  a.gout_off = p->tr_gout; a.gtc_off = p->tr_gtc;
-  a.t = t; a.x_t = x_t; a.cond = cond; a.alpha = alpha; a.beta = beta; a.target = target; a.row_weight = row_weight;
-  a.loss_rows = loss_rows; a.grad = grad_flat; a.fourier_grad = 1;
-  a.rows = rows; a.workspace = (float*)workspace; a.slab_features = p->train_slab_features;
-  hipLaunchKernelGGL(k_loss_f32, dim3(f32_blocks(rows)), dim3(256), 0, st, a);
+  TrainCall c{t, x_t, cond, alpha, beta, target, row_weight, loss_rows, grad_flat, rows};
+  train_step(p, (const float*)packed, c, (float*)workspace, st);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -413,7 +330,6 @@ int grlhip_cep_loss_fwd_bwd(const grlhip_plan* plan, const void* packed, int dty
   if (p->desc.kind != GRLHIP_NET_CONCAT_MLP || p->train_fwd.empty())
     return fail(GRLHIP_ERR_UNSUPPORTED, "cep_loss_fwd_bwd needs a CONCAT_MLP plan");
   if (dtype != GRLHIP_F32) return fail(GRLHIP_ERR_UNSUPPORTED, "cep_loss_fwd_bwd: only GRLHIP_F32 is implemented");
-  if (f32_engine_wave()) return fail(GRLHIP_ERR_UNSUPPORTED, "cep_loss_fwd_bwd runs on the batch engine only (unset GRLHIP_F32_ENGINE)");
   if (group_size < 1 || group_size > TRAIN_CHUNK_ROWS) return fail(GRLHIP_ERR_INVALID, "group_size must be in [1, 65536]");
   if (rows < 0 || rows % group_size) return fail(GRLHIP_ERR_INVALID, "rows must be a multiple of group_size");
   if (rows == 0) return 0;
@@ -435,7 +351,6 @@ int grlhip_net_backward(const grlhip_plan* plan, const void* packed, int dtype, 
   const Plan* p = plan->p;
   if (p->train_fwd.empty()) return fail(GRLHIP_ERR_UNSUPPORTED, "net_backward: the plan has no training programs");
   if (dtype != GRLHIP_F32) return fail(GRLHIP_ERR_UNSUPPORTED, "net_backward: only GRLHIP_F32 is implemented");
-  if (f32_engine_wave()) return fail(GRLHIP_ERR_UNSUPPORTED, "net_backward runs on the batch engine only (unset GRLHIP_F32_ENGINE)");
   if (rows <= 0) return 0;
   const bool qnet = p->desc.kind == GRLHIP_NET_QNET;
   if (qnet) t = nullptr;
@@ -459,7 +374,6 @@ int grlhip_sample_ode_backward(const grlhip_plan* plan, const void* packed, int 
   if (p->desc.kind != GRLHIP_NET_RESNET || p->tr_gx < 0) return fail(GRLHIP_ERR_INVALID, "sample_ode_backward needs a RESNET plan");
   if (p->desc.out_dim != p->desc.x_dim) return fail(GRLHIP_ERR_INVALID, "sample_ode_backward needs out_dim == x_dim");
   if (dtype != GRLHIP_F32) return fail(GRLHIP_ERR_UNSUPPORTED, "sample_ode_backward: only GRLHIP_F32 is implemented");
-  if (f32_engine_wave()) return fail(GRLHIP_ERR_UNSUPPORTED, "sample_ode_backward runs on the batch engine only (unset GRLHIP_F32_ENGINE)");
   if (rows <= 0 || n_steps <= 0) return 0;
   if (!traj || !coef || !grad_traj || !grad_flat) return fail(GRLHIP_ERR_INVALID, "null traj/coef/grad_traj/grad_flat");
   if ((p->desc.cond_dim > 0) != (cond != nullptr))

@@ -1,14 +1,15 @@
 """DPM-Solver (grl/numerical_methods/numerical_solvers/dpm_solver.py:13-905), the solver the QGPO benchmark
 configurations ship with (order 2, 17 function evaluations).
 
-Host-driven: the per-step algebra is a handful of scalar schedule values (half-logSNR, log-scale, std) computed
-on the CPU in fp32 exactly as the reference computes them on tensors, and 1-3 model evaluations per step,
-each of which is the HIP network forward (+ the HIP energy gradient for guided models) through the C ABI.
+The per-step algebra is a handful of scalar schedule values (half-logSNR, log-scale, std) computed on the CPU in
+fp32 exactly as the reference computes them on tensors.  Orders 1-2, and order 3 with ``solver_type="dpm_solver"``,
+become a stage table that ONE ``grlhip_sample_stages`` call runs on the device (``_integrate_fused``); order 3
+"taylor" is stepped from the host, each model evaluation being the HIP forward (+ HIP energy gradient) of the C ABI.
 Supported: ``method="singlestep"`` with orders 1-3, ``type`` "dpm_solver" / "dpm_solver++", ``solver_type``
 "dpm_solver" / "taylor", ``skip_type`` "time_uniform" / "time_quadratic".  The option values on which the
 reference itself fails raise here too (recorded in tests/golden/dpm.npz "raises"): ``skip_type="logSNR"``
 (TypeError), ``denoise=True`` (TypeError), ``method="singlestep_fixed"``; "multistep" and "adaptive" are not
-implemented.  Fusing these stages into the persistent bf16 integrator is the next step."""
+implemented."""
 from typing import List
 
 import torch

@@ -419,17 +419,6 @@ def test_sampling_rows_spanning_two_chunks_vs_oracle():
         close(traj[:, sl], want, what="trajectory rows %s" % (sl,))
 
 
-def test_per_wave_engine_override_matches_goldens():
-    """GRLHIP_F32_ENGINE=wave (the one-launch per-wave interpreter kept for A/B runs) must stay correct: run a
-    slice of this file under it in a child process (the variable is read once per process)."""
-    import os, subprocess, sys
-    env = dict(os.environ, GRLHIP_F32_ENGINE="wave")
-    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-p", "no:cacheprovider", "-k",
-                        "net_forward_vs_golden or losses_and_grads_vs_golden or sde_trajectories_vs_golden or energy_guidance"],
-                       env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-
-
 def test_adam_step_moves_the_loss_down():
     kind, cfg, m = um.build("small_icfm", DEV)
     opt = torch.optim.Adam(m.parameters(), lr=1e-3)
