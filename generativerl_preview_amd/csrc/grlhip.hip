@@ -274,6 +274,55 @@ int grlhip_sample_ode(const grlhip_plan* plan, const void* packed, int dtype, co
                        out_final, out_traj, workspace, workspace_bytes, stream);
 }
 
+// ---- allocation-free variant of grlhip_sample_ode (include/grlhip.h): the fused bf16 integrator with its
+// workspace (per-step Fourier tables, spliced guided weight stream) in a file-scope device array instead of a
+// caller workspace.  In host code `g_static_scratch` is only a stand-in for the symbol: the device address is
+// looked up once per device with hipGetSymbolAddress and only that pointer is ever passed to launches / copies.
+static __device__ __align__(256) unsigned char g_static_scratch[GRLHIP_STATIC_SCRATCH_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[kMaxDevices] = {nullptr};
+
+int static_scratch(void** out) {
+  int dev = -1;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices) return fail(GRLHIP_ERR_UNSUPPORTED, "device ordinal out of range for the static scratch table");
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {  // first call on this device, which is the current one
+    void* ptr = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_static_scratch)));
+    if (!ptr) return fail(GRLHIP_ERR_HIP, "hipGetSymbolAddress returned a null address for the static scratch");
+    g_scratch_ptr[dev] = ptr;
+  }
+  *out = g_scratch_ptr[dev];
+  return 0;
+}
+}  // namespace
+
+size_t grlhip_static_scratch_bytes(void) { return (size_t)GRLHIP_STATIC_SCRATCH_BYTES; }
+
+int grlhip_sample_ode_static(const grlhip_plan* plan, const void* packed, const grlhip_plan* guidance,
+                             const void* guidance_packed, const float* x0, const float* cond, const float* coef,
+                             int32_t n_steps, int64_t rows, float* out_final, float* out_traj, void* stream) {
+  if (int rc = check_ready(plan, packed)) return rc;
+  if (!bf16_fused_ok(plan->p))
+    return fail(GRLHIP_ERR_UNSUPPORTED, "sample_ode_static: only networks with a fused bf16 integrator (GRLHIP_BF16 image) are supported");
+  if (rows > 0) {
+    const size_t need = grlhip_workspace_bytes(plan, guidance, rows, GRLHIP_BF16);
+    if (need > (size_t)GRLHIP_STATIC_SCRATCH_BYTES)
+      return fail(GRLHIP_ERR_WORKSPACE, "sample_ode_static: this call needs " + std::to_string(need) + " bytes of scratch, the static scratch holds " +
+                                            std::to_string((size_t)GRLHIP_STATIC_SCRATCH_BYTES));
+  }
+  void* scratch = nullptr;
+  if (int rc = static_scratch(&scratch)) return rc;
+  // every byte of the scratch the kernels read is rewritten by this call first (Fourier tables by k_temb_table, the
+  // spliced stream by the copies + memset in bf16_sample): nothing has to start at zero
+  return sample_common(plan, packed, GRLHIP_BF16, guidance, guidance_packed, x0, cond, coef, nullptr, n_steps, rows,
+                       out_final, out_traj, scratch, (size_t)GRLHIP_STATIC_SCRATCH_BYTES, stream);
+}
+
 int grlhip_sample_sde(const grlhip_plan* plan, const void* packed, int dtype, const grlhip_plan* guidance,
                       const void* guidance_packed, const float* x0, const float* cond, const float* coef,
                       const float* dW, int32_t n_steps, int64_t rows, float* out_final, float* out_traj,

@@ -1,7 +1,7 @@
 """EnergyConditionalDiffusionModel (QGPO), grl/generative_models/diffusion_model/
 energy_conditional_diffusion_model.py:29-1394: a diffusion model plus an energy-guidance net; guided
 sampling integrates score + guidance_scale * dE/dx, with the Q-gradient evaluated inside the same
-fused step (csrc/engine_f32.hip.inc ``k_sample_f32``)."""
+fused step (csrc/engine_bf16.hip.inc ``guide_grad``; fp32: the batch engine's gradient program)."""
 import torch
 import torch.nn as nn
 

@@ -148,6 +148,21 @@ int grlhip_sample_ode(const grlhip_plan* plan, const void* packed, int dtype,
                       int64_t rows, float* out_final, float* out_traj,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* No counterpart in the reference.  For callers that cannot allocate device memory or hand over a workspace --
+ * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc: grlhip_sample_ode on the fused
+ * bf16 integrator (GRLHIP_BF16 images of networks that have one; anything else: GRLHIP_ERR_UNSUPPORTED) with the
+ * workspace (per-step Fourier tables, spliced guided weight stream) in a device array of GRLHIP_STATIC_SCRATCH_BYTES
+ * that is part of the library's code object.  Each GPU the library runs on holds its own copy until the process ends.
+ * The call performs no hipMalloc / hipFree; a call whose scratch need (grlhip_workspace_bytes for GRLHIP_BF16)
+ * exceeds the array returns GRLHIP_ERR_WORKSPACE.  Every call on a GPU shares that GPU's array: calls that overlap
+ * on one GPU (different streams or threads) race -- serialise them, or use grlhip_sample_ode with workspaces. */
+#define GRLHIP_STATIC_SCRATCH_BYTES (6u << 20)
+size_t grlhip_static_scratch_bytes(void);
+int grlhip_sample_ode_static(const grlhip_plan* plan, const void* packed,
+                             const grlhip_plan* guidance, const void* guidance_packed,
+                             const float* x0, const float* cond, const float* coef, int32_t n_steps,
+                             int64_t rows, float* out_final, float* out_traj, void* stream);
+
 /* Replaces: SDESolver.integrate -> torchsde.sdeint(method="euler")
  * (grl/numerical_methods/numerical_solvers/sde_solver.py:92-144) for the reverse SDE closures
  * (diffusion_process.py:742-851): Euler-Maruyama y += f*dt + g*dW with the Brownian increments read
