@@ -108,6 +108,51 @@ def make_weights(model_name, key_shapes):
     return out
 
 
+# VP-path models whose weights are TRAINED (a few hundred Adam steps of the reference's own loss on a bounded toy set,
+# make_trained_weights.py) and stored in weights_<name>.npz: with the seeded init above the VP reverse ODE amplifies
+# the state by exp(0.5 * int beta) ~ 150 over [0, 1], so sampled "actions" end at |x| ~ 300 and a max-abs criterion
+# on them says nothing.  Trained nets keep |x| = O(1), as a real policy does.
+# Not trained: small_vp_score (the reference's score-head loss regresses score * sigma onto +eps, score_function.py
+# :206-217 as written, so training drives the reverse ODE to diverge: 2e12 after 100 steps), small_vp_data (no loss
+# of the reference accepts a data-prediction head), small_gvp_score (tan(pi/2) at the first step).  Those keep the
+# seeded init and their trajectory checks stay RELATIVE to max|ref|.
+TRAINED = ("qgpo_noise", "swiss_noise", "small_vp_noise", "small_vp_velocity", "small_energy", "small_uncond_noise")
+
+
+def toy_data(name, rows, x_dim, cond_dim, seed):
+    """Bounded toy training set: x in [-1, 1]^D, a smooth function of the condition (or one bent blob)."""
+    rs = np.random.RandomState(_seed_for(name + "/toy", seed))
+    if cond_dim:
+        A = np.random.RandomState(_seed_for(name + "/toyA", 0)).randn(cond_dim, x_dim) / np.sqrt(cond_dim)
+        cond = rs.randn(rows, cond_dim)
+        x = 0.9 * np.tanh(1.5 * cond @ A) + 0.05 * rs.randn(rows, x_dim)
+        return x.astype(np.float32), cond.astype(np.float32)
+    # unconditional: ONE smooth, bent ("banana") blob.  A multi-modal target makes the sampling ODE bifurcate between
+    # modes, where rounding-level differences grow without bound -- that tests chaos, not kernels.
+    z = rs.randn(rows, x_dim)
+    x = 0.3 * z
+    x[:, 0] = 0.5 * z[:, 0]
+    if x_dim >= 2:
+        x[:, 1] = 0.25 * z[:, 1] + 0.2 * (z[:, 0] ** 2 - 1.0)
+    return np.clip(x, -1.0, 1.0).astype(np.float32), None
+
+
+def load_weights(model_name, key_shapes, golden_dir=None):
+    """The weights the goldens were produced with: the stored trained ones for TRAINED models, else the seeded init."""
+    import os
+    golden_dir = golden_dir or os.path.dirname(os.path.abspath(__file__))
+    path = os.path.join(golden_dir, "weights_%s.npz" % model_name)
+    if model_name in TRAINED and os.path.exists(path):
+        z = np.load(path)
+        out = {}
+        for key, shape in key_shapes:
+            w = z[key]
+            assert tuple(w.shape) == tuple(shape), (key, w.shape, shape)
+            out[key] = np.ascontiguousarray(w, dtype=np.float32)
+        return out
+    return make_weights(model_name, key_shapes)
+
+
 def make_inputs(tag, rows, x_dim, cond_dim=None):
     rs = np.random.RandomState(_seed_for(tag, 1))
     d = dict(x=rs.randn(rows, x_dim).astype(np.float32),

@@ -53,7 +53,7 @@ def build(name):
     else:
         m = IndependentConditionalFlowModel(cfg)
     key_shapes = [(k, list(v.shape)) for k, v in m.state_dict().items()]
-    w = gl.make_weights(name, key_shapes)
+    w = gl.load_weights(name, key_shapes)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
     return kind, cfg, m, key_shapes
 

@@ -34,7 +34,7 @@ for name, B, K, alpha in (("small_energy", 6, 4, 1.0), ("qgpo_noise", 5, 16, 3.0
     cfg = EasyDict(cfg)
     m = EnergyConditionalDiffusionModel(cfg, energy_model=ToyEnergy())
     m.alpha = alpha
-    w = gl.make_weights(name, [(k, list(v.shape)) for k, v in m.state_dict().items()])
+    w = gl.load_weights(name, [(k, list(v.shape)) for k, v in m.state_dict().items()])
     m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
     for p in m.energy_guidance.parameters():     # also the Fourier frequencies (requires_grad=False by default)
         p.requires_grad_(True)

@@ -46,7 +46,7 @@ def build(name):
     cfg = EasyDict(cfg)
     m = DiffusionModel(cfg) if kind == "diffusion" else EnergyConditionalDiffusionModel(cfg, energy_model=None)
     key_shapes = [(k, list(v.shape)) for k, v in m.state_dict().items()]
-    w = gl.make_weights(name, key_shapes)
+    w = gl.load_weights(name, key_shapes)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
     return kind, cfg, m
 

@@ -24,7 +24,7 @@ def model_info(name):
 
 def weights(name, as_torch=True):
     info = MANIFEST["models"][name]
-    w = gl.make_weights(name, [(k, tuple(s)) for k, s in info["key_shapes"]])
+    w = gl.load_weights(name, [(k, tuple(s)) for k, s in info["key_shapes"]], GOLDEN)
     if as_torch:
         return {k: torch.from_numpy(v) for k, v in w.items()}
     return w

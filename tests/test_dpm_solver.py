@@ -36,12 +36,24 @@ def _cases(g, name):
                             skip_type=skip, denoise=False), gs
 
 
-def close(a, b, tol, what):
+def _rel(name, key):
+    """Goldens whose reference values are not O(1) by construction: small_vp_score (golden_lib.TRAINED comment) and
+    dpm_solver++ on the energy-guided models (the reference's guided data prediction is, as written, (-std x + cov
+    score) / scale, energy_conditional_diffusion_model.py:1281-1306, which diverges)."""
+    return name == "small_vp_score" or (name in ("small_energy", "qgpo_noise") and ("solverpp" in key or "solver++" in key))
+
+
+def close(a, b, tol, what, rel=False):
+    """Absolute max-abs tolerance (the DPM goldens of the trained VP models are O(1) actions); rel=True only for
+    small_vp_score, whose reference trajectory diverges by construction (golden_lib.TRAINED comment)."""
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     assert a.shape == b.shape, (what, a.shape, b.shape)
-    scale = max(1.0, float(np.abs(b).max()))
+    ref = float(np.abs(b).max())
+    scale = max(1.0, ref) if rel else 1.0
     err = float(np.abs(a - b).max())
-    assert err <= tol * scale, "%s: max-abs err %.3e (scale %.2e)" % (what, err, scale)
+    line = "[parity] %-60s max-abs err %.3e  max|ref| %.3e  tol %.1e%s" % (what, err, ref, tol, " x max|ref|" if rel else " abs")
+    print(line)
+    assert err <= tol * scale, line
 
 
 @pytest.mark.parametrize("name", MODELS)
@@ -64,7 +76,7 @@ def test_oracle_dpm_solver_vs_reference_golden(name):
             data_fn = lambda t, x: O.data_head(mt, path, net(t, x), t, x)  # noqa: E731
         with torch.enable_grad():
             out = O.dpm_solver_integrate(path, noise_fn, data_fn, x0, **kw)
-        close(out.detach(), g[key], 2e-5, key)
+        close(out.detach(), g[key], 2e-5, name + " " + key, rel=_rel(name, key))
         n += 1
     assert n >= 6
     assert any(r.startswith(name + "/") for r in g["raises"])  # the reference's own failing option sets are recorded
@@ -118,8 +130,8 @@ def test_gpu_dpm_solver_vs_reference_golden(name):
         if gs is not None:
             call["guidance_scale"] = gs
         traj = m.sample_forward_process(**call)
-        close(traj.cpu(), g[key], 2e-4, key)
-        close(m.sample(**call).cpu(), g[key][-1], 2e-4, key + " final")
+        close(traj.cpu(), g[key], 1e-4, name + " " + key, rel=_rel(name, key))
+        close(m.sample(**call).cpu(), g[key][-1], 1e-4, name + " " + key + " final", rel=_rel(name, key))
         n += 1
     assert n >= 6
 
@@ -150,27 +162,28 @@ def test_gpu_fused_stages_equal_host_driven_stages_and_bf16_runs_in_the_persiste
             nf, df = m._dpm_functions(1.0)
             host = solver.integrate(m.diffusion_process, nf, df, x0.to(DEV), cond.to(DEV), save_intermediate=True)
             assert solver.nfe == 17
-            close(fused.cpu(), host.cpu(), 2e-5, "fused vs host-driven %s order %d" % (typ, order))
+            close(fused.cpu(), host.cpu(), 2e-5, "fused vs host-driven %s order %d" % (typ, order), rel="++" in typ)
         n_fused = len(calls)
         m.sample_forward_process(x_0=x0.to(DEV), condition=cond.to(DEV), guidance_scale=1.0, solver_config=dict(
             type="DPMSolver", args=dict(order=3, device=DEV, steps=9, type="dpm_solver", solver_type="taylor")))
         assert len(calls) == n_fused   # the taylor form of order 3 needs two saved model values: host-driven
-        # bf16: the persistent integrator; dpm_solver++ keeps the states O(1)
+        # bf16: the persistent integrator, on the O(1) noise-prediction form (the guided data-prediction form of
+        # dpm_solver++ diverges as written in the reference, see _rel)
         path, mt = O.Path(cfg["path"]), cfg["model"]["type"]
         score = lambda t, x: O.guided_score(sd, mt, path, t, x, cond, 1.0)  # noqa: E731
         noise_fn = lambda t, x: -score(t, x) * O._b(path.std(t), x)  # noqa: E731
         data_fn = lambda t, x: (-O._b(path.std(t), x) * x + O._b(path.cov(t), x) * score(t, x)) / O._b(path.scale(t), x)  # noqa: E731
         with torch.enable_grad():
-            want = O.dpm_solver_integrate(path, noise_fn, data_fn, x0, steps=17, order=2, type="dpm_solver++")
+            want = O.dpm_solver_integrate(path, noise_fn, data_fn, x0, steps=17, order=2, type="dpm_solver")
         m.model.compute_dtype = L.BF16
         n0 = len(calls)
         got = m.sample_forward_process(x_0=x0.to(DEV), condition=cond.to(DEV), guidance_scale=1.0,
-                                       solver_config=dict(type="DPMSolver", args=dict(order=2, device=DEV, steps=17, type="dpm_solver++")))
+                                       solver_config=dict(type="DPMSolver", args=dict(order=2, device=DEV, steps=17, type="dpm_solver")))
         assert calls[n0:] == [L.BF16]
-        close(got.cpu(), want.detach(), 2e-2, "bf16 fused DPM-Solver++ trajectory")
+        close(got.cpu(), want.detach(), 2e-2, "bf16 fused DPM-Solver-2 trajectory", rel=True)
         close(m.sample(x_0=x0.to(DEV), condition=cond.to(DEV), guidance_scale=1.0,
-                       solver_config=dict(type="DPMSolver", args=dict(order=2, device=DEV, steps=17, type="dpm_solver++"))).cpu(),
-              want[-1].detach(), 2e-2, "bf16 fused DPM-Solver++ final")
+                       solver_config=dict(type="DPMSolver", args=dict(order=2, device=DEV, steps=17, type="dpm_solver"))).cpu(),
+              want[-1].detach(), 2e-2, "bf16 fused DPM-Solver-2 final")
     finally:
         engine.NetPlan.sample_stages = orig
 
@@ -219,4 +232,4 @@ def test_stage_table_reproduces_the_solver_on_the_cpu(name, typ, order, steps):
     want = O.dpm_solver_integrate(path, nf, df, x0, steps=steps, order=order, type=typ)
     got = torch.stack(traj)
     assert got.shape == want.shape
-    close(got.detach(), want.detach(), 2e-4, "stage table vs oracle solver")
+    close(got.detach(), want.detach(), 2e-4, "stage table vs oracle solver", rel=_rel(name, typ))

@@ -1,5 +1,15 @@
 """GPU parity: the HIP path (through the C ABI) against the committed goldens and against the CPU
-oracle on larger seeded inputs.  fp32 engine tolerance: max-abs 1e-4 on O(1) states (north_star)."""
+oracle on larger seeded inputs.
+
+Tolerances (north_star): final actions / trajectories ABSOLUTE max-abs 1e-4 (fp32 engine) and 2e-2 (bf16 engine) -- the
+VP golden models carry trained weights (tests/golden/make_trained_weights.py) so that sampled actions are O(1) and
+an absolute criterion means something; losses 1e-5 relative.  ``rel=True`` (tolerance x max(1, max|ref|)) is used
+only where the checked quantity is not an action: gradients (scale of the tensor), head conversions / guided scores
+(they carry 1/sigma factors) and the three goldens whose reference trajectories diverge by construction
+(golden_lib.TRAINED comment: small_vp_score, small_vp_data, small_gvp_score).  Every comparison prints its achieved
+error and appends it to gpurun_out/parity_errors.log."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -16,13 +26,27 @@ ALL = gu.CANON + gu.SMALL
 TOL = 1e-4  # north_star: fp32 final actions within max-abs 1e-4
 
 
-def close(a, b, tol=TOL, what=""):
+REL_TRAJ = ("small_vp_score", "small_vp_data", "small_gvp_score")  # reference trajectories diverge by construction
+_LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_errors.log")
+
+
+def close(a, b, tol=TOL, what="", rel=False):
     a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float64)
     b = b.detach().cpu().double().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, dtype=np.float64)
     assert a.shape == b.shape, (what, a.shape, b.shape)
-    scale = max(1.0, float(np.max(np.abs(b))))
-    err = float(np.max(np.abs(a - b)))
-    assert err <= tol * scale, "%s: max-abs err %.3e (scale %.2e, tol %.1e)" % (what, err, scale, tol)
+    ref = float(np.max(np.abs(b))) if b.size else 0.0
+    scale = max(1.0, ref) if rel else 1.0
+    err = float(np.max(np.abs(a - b))) if b.size else 0.0
+    line = "[parity] %-60s max-abs err %.3e  max|ref| %.3e  tol %.1e%s  %s" % (
+        what, err, ref, tol, " x max|ref|" if rel else " abs", os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0])
+    print(line)
+    try:
+        os.makedirs(os.path.dirname(_LOG), exist_ok=True)
+        with open(_LOG, "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+    assert err <= tol * scale, line
 
 
 def cu(a):
@@ -38,7 +62,7 @@ def test_net_forward_vs_golden(name):
     kind, cfg, m = um.build(name, DEV)
     g = gu.load("model_%s.npz" % name)
     out = m.model(cu(g["t"]), cu(g["x"]), cu(g.get("cond")))
-    close(out, g["net"], what="net")
+    close(out, g["net"], what=name + " net")
 
 
 @pytest.mark.parametrize("name", [n for n in ALL if not n.endswith("icfm") and n != "icfm_cond"])
@@ -52,7 +76,7 @@ def test_head_conversions_vs_golden(name):
     for h, fn in (("score", m.score_function), ("noise", m.noise_function), ("velocity", m.velocity_function),
                   ("data", m.data_prediction_function)):
         if "head_" + h in g:
-            close(fn(t, x, c), g["head_" + h], tol=2e-4, what="head_" + h)
+            close(fn(t, x, c), g["head_" + h], tol=2e-4, what=name + " head_" + h, rel=True)
             n += 1
         else:
             with pytest.raises(NotImplementedError):
@@ -65,10 +89,10 @@ def test_energy_guidance_vs_golden(name):
     kind, cfg, m = um.build(name, DEV)
     g = gu.load("model_%s.npz" % name)
     t, x, c = cu(g["t"]), cu(g["x"]), cu(g["cond"])
-    close(m.energy_guidance(t, x, c), g["energy"], what="energy")
+    close(m.energy_guidance(t, x, c), g["energy"], what=name + " energy")
     for s in (0.0, 1.0, 5.0):
-        close(m.energy_guidance.calculate_energy_guidance(t, x, c, s), g["guidance_%g" % s], what="guidance")
-        close(m.score_function_with_energy_guidance(t, x, c, s), g["guided_score_%g" % s], what="guided score")
+        close(m.energy_guidance.calculate_energy_guidance(t, x, c, s), g["guidance_%g" % s], what=name + " guidance")
+        close(m.score_function_with_energy_guidance(t, x, c, s), g["guided_score_%g" % s], what=name + " guided score", rel=True)
 
 
 def _cases(s):
@@ -95,9 +119,9 @@ def test_ode_trajectories_vs_golden(name):
         if not use_x0:
             um.fix_noise(m, cu(s["xT_T%d_b%s_x0" % (Tn, bs)]))
         traj = m.sample_forward_process(**kw)
-        close(traj, s[key], what=key)
+        close(traj, s[key], what=name + " " + key, rel=name in REL_TRAJ)
         final = m.sample(**kw)
-        close(final, s[key][-1], what=key + " final")
+        close(final, s[key][-1], what=name + " " + key + " final", rel=name in REL_TRAJ)
         n += 1
     assert n >= 4
 
@@ -118,7 +142,7 @@ def test_sde_trajectories_vs_golden(name):
             if "_g" in key:
                 kw["guidance_scale"] = float(key.split("_g")[1])
             um.fix_noise(m, cu(s["sde_T%d_xT" % Tn]))
-            close(m.sample_forward_process(**kw), s[key], what=key, tol=2e-4)
+            close(m.sample_forward_process(**kw), s[key], what=name + " " + key)
             n += 1
     assert n >= 2
 
@@ -144,7 +168,7 @@ def test_ode_sampling_vs_oracle_ragged_rows(name, rows):
     got = m.sample(**kw)
     want = O.sample_forward_process(sd, cfg, kind, t_span, x_0=x0, condition=cond, guidance_scale=1.5)[-1]
     assert got.shape == want.shape
-    close(got, want, what=name)
+    close(got, want, what=name + " 20-step finals vs oracle", rel=name in REL_TRAJ)
 
 
 def test_empty_batch_and_errors():
@@ -204,7 +228,7 @@ def test_bf16_ode_sampling_vs_oracle(name, rows, steps):
     tail = slice(max(0, rows - 64), rows)
     for sl in (chunk, tail):
         want = O.sample_forward_process(sd, cfg, kind, t_span, x_0=x0[sl], condition=None if cond is None else cond[sl])[-1]
-        close(got[sl], want, tol=BF16_TOL, what="bf16 %s" % name)
+        close(got[sl], want, tol=BF16_TOL, what="bf16 %s %d rows %d steps finals" % (name, rows, steps))
 
 
 def test_bf16_trajectory_and_sde_vs_golden():
@@ -215,13 +239,16 @@ def test_bf16_trajectory_and_sde_vs_golden():
         kw = dict(t_span=torch.linspace(0.0, 1.0, Tn), batch_size=bs, x_0=cu(s["x0"]) if use_x0 else None)
         if not use_x0:
             um.fix_noise(m, cu(s["xT_T%d_b%s_x0" % (Tn, bs)]))
-        close(m.sample_forward_process(**kw), s[key], tol=BF16_TOL, what="bf16 " + key)
+        traj = m.sample_forward_process(**kw)
+        close(traj, s[key], tol=BF16_TOL, what="bf16 swiss trajectory " + key, rel=True)
+        close(traj[-1], s[key][-1], tol=BF16_TOL, what="bf16 swiss final " + key)
     for Tn, dt in ((11, 0.1), (21, 0.05)):
         um.fix_noise(m, cu(s["sde_T%d_xT" % Tn]))
         out = m.sample_forward_process(t_span=torch.linspace(0.0, 1.0, Tn), batch_size=2,
                                        solver_config=dict(type="SDESolver", args=dict(library="torchsde", dt=dt)),
                                        noise_increments=cu(s["sde_T%d_dW" % Tn]))
-        close(out, s["sde_T%d" % Tn], tol=BF16_TOL, what="bf16 sde")
+        close(out, s["sde_T%d" % Tn], tol=BF16_TOL, what="bf16 swiss sde trajectory T%d" % Tn, rel=True)
+        close(out[-1], s["sde_T%d" % Tn][-1], tol=BF16_TOL, what="bf16 swiss sde final T%d" % Tn)
 
 
 def _bf16_energy_model():
@@ -241,7 +268,7 @@ def test_bf16_guided_sampling_vs_golden():
                   condition=cu(s["cond"]), guidance_scale=gs)
         if not use_x0:
             um.fix_noise(m, cu(s["xT_T%d_b%s_x0" % (Tn, bs)]))
-        close(m.sample_forward_process(**kw), s[key], tol=BF16_TOL, what="bf16 guided " + key)
+        close(m.sample_forward_process(**kw), s[key], tol=BF16_TOL, what="bf16 guided trajectory " + key, rel=True)
         close(m.sample(**kw), s[key][-1], tol=BF16_TOL, what="bf16 guided final " + key)
         n += 1
     assert n >= 8
@@ -252,10 +279,11 @@ def test_bf16_guided_sampling_vs_golden():
                                            guidance_scale=float(gs),
                                            solver_config=dict(type="SDESolver", args=dict(library="torchsde", dt=dt)),
                                            noise_increments=cu(s["sde_T%d_dW" % Tn]))
-            close(out, s["sde_T%d_g%d" % (Tn, gs)], tol=BF16_TOL, what="bf16 guided sde")
+            close(out, s["sde_T%d_g%d" % (Tn, gs)], tol=BF16_TOL, what="bf16 guided sde trajectory T%d g%d" % (Tn, gs), rel=True)
+            close(out[-1], s["sde_T%d_g%d" % (Tn, gs)][-1], tol=BF16_TOL, what="bf16 guided sde final T%d g%d" % (Tn, gs))
 
 
-@pytest.mark.parametrize("rows,steps,scale", [(1000, 100, 1.0), (128 * 260 + 37, 10, 3.0)])
+@pytest.mark.parametrize("rows,steps,scale", [(1000, 100, 10.0), (128 * 260 + 37, 10, 30.0)])
 def test_bf16_guided_ode_vs_oracle(rows, steps, scale):
     cfg, m, sd = _bf16_energy_model()
     gen = torch.Generator().manual_seed(23)
@@ -263,14 +291,18 @@ def test_bf16_guided_ode_vs_oracle(rows, steps, scale):
     cond = torch.randn(rows, 17, generator=gen)
     t_span = torch.linspace(0.0, 1.0, steps + 1)
     got = m.sample(t_span=t_span, x_0=x0.to(DEV), condition=cond.to(DEV), guidance_scale=scale).cpu()
-    ref32 = None
+    worst = 0.0
     for sl in (slice(0, min(rows, 1024)), slice(max(0, rows - 64), rows)):
         want = O.sample_forward_process(sd, cfg, "energy", t_span, x_0=x0[sl], condition=cond[sl], guidance_scale=scale)[-1]
-        close(got[sl], want, tol=BF16_TOL, what="bf16 guided")
-    # the guidance term must matter at this scale (otherwise the test proves nothing)
+        close(got[sl], want, tol=BF16_TOL, what="bf16 guided %d rows %d steps scale %g" % (rows, steps, scale))
+        worst = max(worst, float((got[sl] - want).abs().max()))
+    # the guidance term must matter at this scale (otherwise the test proves nothing): leaving it out moves the
+    # actions by several times the error the guided kernel makes
     un = O.sample_forward_process(sd, cfg, "energy", t_span, x_0=x0[:64], condition=cond[:64], guidance_scale=0.0)[-1]
     gd = O.sample_forward_process(sd, cfg, "energy", t_span, x_0=x0[:64], condition=cond[:64], guidance_scale=scale)[-1]
-    assert float(np.max(np.abs(np.asarray(un) - np.asarray(gd)))) > 5 * BF16_TOL
+    effect = float(np.max(np.abs(np.asarray(un) - np.asarray(gd))))
+    print("[parity] guidance effect %.3e vs worst bf16 error %.3e" % (effect, worst))
+    assert effect > 4 * worst and effect > BF16_TOL, (effect, worst)
 
 
 @pytest.mark.parametrize("name,rows,steps", [("small_vp_noise", 333, 20), ("gvp_wide", 300, 20), ("small_uncond_noise", 130, 50),
@@ -314,11 +346,11 @@ def _check_grads(m, g, pfx):
             continue
         assert p.grad is not None, k
         if pfx + "_grad/" + k in g:
-            close(p.grad, g[pfx + "_grad/" + k], tol=2e-4, what=pfx + " grad " + k)
+            close(p.grad, g[pfx + "_grad/" + k], tol=2e-4, what=pfx + " grad " + k, rel=True)
             n += 1
         elif pfx + "_gradsub/" + k in g:
             flat = p.grad.reshape(-1)
-            close(flat[:: max(1, flat.numel() // 509)][:509], g[pfx + "_gradsub/" + k], tol=2e-4, what=pfx + " grad " + k)
+            close(flat[:: max(1, flat.numel() // 509)][:509], g[pfx + "_gradsub/" + k], tol=2e-4, what=pfx + " grad " + k, rel=True)
             s = g[pfx + "_gradsum/" + k]
             assert abs(float(flat.double().pow(2).sum().sqrt()) - s[1]) <= 2e-4 * s[1] + 1e-7, k
             n += 1
@@ -350,7 +382,7 @@ def test_losses_and_grads_vs_golden(name):
         loss.backward()
         _check_grads(m, g, pfx)
         rows = call(False)
-        close(rows, g[pfx + "_loss_rows"], tol=2e-5, what=pfx + " rows")
+        close(rows, g[pfx + "_loss_rows"], tol=2e-5, what=pfx + " rows", rel=True)
 
 
 def test_weighted_rows_backward_and_trainable_fourier():
@@ -374,7 +406,7 @@ def test_weighted_rows_backward_and_trainable_fourier():
     grads = dict(zip(keys, torch.autograd.grad((ref * w).sum(), [sd[k] for k in keys])))
     for k, p in m.named_parameters():
         if k.startswith("model."):
-            close(p.grad, grads[k], tol=3e-4, what=k)
+            close(p.grad, grads[k], tol=3e-4, what=k, rel=True)
 
 
 def test_training_batch_spanning_two_chunks_vs_oracle():
@@ -394,12 +426,12 @@ def test_training_batch_spanning_two_chunks_vs_oracle():
         sd[k].requires_grad_(True)
     ref = O.icfm_flow_matching_loss(lambda tt, y: O.intrinsic_forward(sd, tt, y, cond), x0, x1, t, eps,
                                     cfg["path"]["sigma"], average=False)
-    close(rows, ref.detach(), tol=2e-5, what="loss rows")
+    close(rows, ref.detach(), tol=2e-5, what="loss rows", rel=True)
     grads = dict(zip(keys, torch.autograd.grad(ref.mean(), [sd[k] for k in keys])))
     n = 0
     for k, p in m.named_parameters():
         if k in grads:
-            close(p.grad, grads[k], tol=3e-4, what=k)
+            close(p.grad, grads[k], tol=3e-4, what=k, rel=True)
             n += 1
     assert n > 10
 
