@@ -4,10 +4,14 @@ HalfCheetah-shaped policy (obs 17, act 6, TemporalSpatialResidualNet [512,256,12
 noise head), 1 048 576 synthetic states x 32 candidate actions PER GPU, through
 ``DiffusionModel.sample`` -> C ABI -> the bf16 MFMA persistent integrator.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-One "step" = one full pass (all rows, all 100 solver steps).  Prints ONE JSON line on rank 0.
-Sampling shards by state blocks; there is no data-path collective (scaling: weak).
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ...` (RANK / WORLD_SIZE in the
+environment) or started plainly, in which case this process spawns the N rank processes itself before touching the
+GPU (generativerl_preview_amd/launch.py).  One "step" = one full pass (all rows, all 100 solver steps).  Prints ONE
+JSON line on rank 0.  Sampling shards by state blocks; there is no data-path collective (scaling: weak).
+`--dry` (tests): gloo on CPU, the HIP step replaced by a stub -- exercises spawn, rendezvous, barriers, the
+MAX-over-ranks timing and the JSON line without a GPU.
 """
 import argparse
 import json
@@ -51,11 +55,31 @@ def build_model(device):
     return m
 
 
-def cpu_baseline(model, rows=32768, chunk=4096):
+def cpu_info():
+    model, phys = "unknown", set()
+    try:
+        pid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                phys.add((pid, line.split(":", 1)[1].strip()))
+    except OSError:
+        pass
+    return model, len(phys) or None, os.cpu_count()
+
+
+def cpu_threads():
+    return min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+
+
+def cpu_baseline(model, rows=65536, chunk=4096):
     """The CPU oracle (port of the reference's torch path) on a bounded sample of the same workload:
     `rows` rows x 100 Euler steps, chunked at 4096 like the reference's generate_fake_action."""
     from oracle import grl_oracle as O
-    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    threads = cpu_threads()
     torch.set_num_threads(threads)
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     cfg = qgpo_config("cpu")
@@ -68,25 +92,136 @@ def cpu_baseline(model, rows=32768, chunk=4096):
         for i in range(0, rows, chunk):
             O.sample_forward_process(sd, cfg, "diffusion", t_span, x_0=x0[i:i + chunk], condition=cond[i:i + chunk])
     dt = time.time() - t0
+    cpu, phys, logical = cpu_info()
     return dict(value=rows / dt, unit="samples/s", cores=threads, kind="port",
                 sample="%d rows x %d Euler steps (chunks of %d), oracle/grl_oracle.py eager fp32 torch, %.1f s"
                        % (rows, N_SOLVER_STEPS, chunk, dt),
+                cpu_model=cpu, physical_cores=phys, logical_cores=logical, threads=threads,
                 action_steps_per_s=rows * N_SOLVER_STEPS / dt)
 
 
+PMC_PROFILE = "profiles/r02_bench_pmc.json"
+
+
 def pmc_traffic(rows):
-    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (separate --pmc runs of this script at
-    131072 states = 4194304 rows: scripts/profile_bench.sh), scaled linearly to this launch's rows: the counters
-    cannot be read from inside the timed run.  2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, KB -> bytes."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_bench_bf16_v3.json")
+    """HBM-side bytes per launch of k_sample_bf16 from the committed rocprofv3 PMC passes (separate --pmc runs of this
+    script, counters summed over the k_sample_bf16 dispatches only: scripts/profile_bench.sh), scaled linearly to this
+    launch's rows: the counters cannot be read from inside the timed run.  2 x FETCH_SIZE (gfx950 correction) +
+    WRITE_SIZE, KB -> bytes."""
+    path = os.path.join(ROOT, PMC_PROFILE)
     try:
         with open(path) as f:
-            prof = json.load(f)
-        pm = next(v for k, v in prof.items() if k.startswith("pmc"))
-        per_row = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0 / 4194304.0
-        return per_row * rows, "profiles/r01_bench_bf16_v3.json (separate PMC passes, scaled by rows)"
+            pm = json.load(f)["pmc_k_sample_bf16"]
+        per_row = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0 / pm["rows"]
+        return per_row * rows, PMC_PROFILE + " (separate PMC passes filtered to k_sample_bf16, scaled by rows)"
     except Exception:  # noqa: BLE001 -- the profile is optional
         return None, None
+
+
+def _time_gpu(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps, out
+
+
+def secondary_results(device, model):
+    """Other BASELINE configs / engines on the same box, one object each (never the headline): the fp32 engine on the
+    C2 net (the precision trade), C5 (GVP [1024] D=64, 100-step ODE, batch 262144) and C3 (ICFM training step, batch
+    65536, fwd+bwd+Adam).  Small enough to add ~10 s to the run."""
+    import generativerl_preview_amd as G
+    from generativerl_preview_amd import _lib as L
+    res = []
+    t_span = torch.linspace(0.0, 1.0, N_SOLVER_STEPS + 1)
+    gen = torch.Generator(device=device).manual_seed(7)
+    try:   # fp32 batch engine on the C2 net
+        rows = 262144
+        x0 = torch.randn(rows, 6, device=device, generator=gen)
+        cond = torch.randn(rows, 17, device=device, generator=gen)
+        model.model.compute_dtype = L.F32
+        dt, _ = _time_gpu(lambda: model.sample(t_span=t_span, x_0=x0, condition=cond), 1)
+        model.model.compute_dtype = L.BF16
+        tf = rows * N_SOLVER_STEPS * FLOP_PER_ACTION_STEP / dt / 1e12
+        res.append({"name": "fp32_engine", "workload": "C2 net, %d rows x 100-step Euler ODE on the fp32 batch engine" % rows,
+                    "dtype": "f32", "value": rows / dt, "unit": "samples/s", "action_steps_per_s": rows * N_SOLVER_STEPS / dt,
+                    "roofline": {"bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3}})
+    except Exception as e:  # noqa: BLE001
+        res.append({"name": "fp32_engine", "error": repr(e)})
+    try:   # C5: GVP velocity net [1024], D = 64
+        t_enc = dict(type="GaussianFourierProjectionTimeEncoder", args=dict(embed_dim=32, scale=30.0))
+        cfg = dict(device=device, x_size=64, alpha=1.0, path=dict(type="gvp"),
+                   solver=dict(type="ODESolver", args=dict(library="torchdyn")),
+                   model=dict(type="velocity_function", args=dict(t_encoder=t_enc, backbone=dict(
+                       type="TemporalSpatialResidualNet", args=dict(hidden_sizes=[1024], output_dim=64, t_dim=32)))))
+        torch.manual_seed(0)
+        m5 = G.DiffusionModel(cfg).to(device)
+        m5.model.compute_dtype = L.BF16
+        rows = 262144
+        x0 = torch.randn(rows, 64, device=device, generator=gen)
+        dt, _ = _time_gpu(lambda: m5.sample(t_span=t_span, x_0=x0), 2)
+        tf = rows * N_SOLVER_STEPS * 6950912 / dt / 1e12
+        res.append({"name": "C5_gvp_wide", "workload": "C5 GVP velocity net [1024], D=64, batch %d, 100-step Euler ODE" % rows,
+                    "dtype": "bf16", "value": rows / dt, "unit": "samples/s", "action_steps_per_s": rows * N_SOLVER_STEPS / dt,
+                    "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": tf / PEAK_BF16_TFLOPS}})
+        del m5, x0
+    except Exception as e:  # noqa: BLE001
+        res.append({"name": "C5_gvp_wide", "error": repr(e)})
+    try:   # C3: ICFM training step
+        cfg = dict(device=device, x_size=6, alpha=1.0, path=dict(sigma=0.1),
+                   solver=dict(type="ODESolver", args=dict(library="torchdyn")),
+                   model=qgpo_config(device)["model"])
+        cfg["model"] = dict(cfg["model"], type="velocity_function")
+        torch.manual_seed(0)
+        m3 = G.IndependentConditionalFlowModel(cfg).to(device)
+        opt = torch.optim.Adam(m3.parameters(), lr=1e-4)
+        B = 65536
+        x1 = torch.rand(B, 6, device=device, generator=gen) * 2 - 1
+        cond = torch.randn(B, 17, device=device, generator=gen)
+
+        def train_step():
+            opt.zero_grad(set_to_none=False)
+            loss = m3.flow_matching_loss(torch.randn(B, 6, device=device, generator=gen), x1, cond)
+            loss.backward()
+            opt.step()
+            return loss
+        for _ in range(2):
+            train_step()
+        dt, loss = _time_gpu(train_step, 10)
+        tf = B * 9759936 / dt / 1e12
+        entry = {"name": "C3_icfm_train", "workload": "C3 GMPO ICFM flow_matching_loss fwd+bwd+Adam, batch %d, 1 GPU" % B,
+                 "dtype": "f32", "value": B / dt, "unit": "rows/s", "ms_per_step": dt * 1e3, "final_loss": float(loss.detach()),
+                 "roofline": {"bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3}}
+        try:   # the same step on the host cores through the oracle (bounded sample)
+            from oracle import grl_oracle as O
+            torch.set_num_threads(cpu_threads())
+            sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and not k.endswith("t_encoder.W"))
+                  for k, v in m3.state_dict().items()}
+            Bc = 8192
+            g = torch.Generator().manual_seed(3)
+            cx0, cx1, cc = torch.randn(Bc, 6, generator=g), torch.rand(Bc, 6, generator=g) * 2 - 1, torch.randn(Bc, 17, generator=g)
+            ct, ce = torch.rand(Bc, generator=g), torch.randn(Bc, 6, generator=g)
+            leaves = [v for v in sd.values() if v.requires_grad]
+            copt = torch.optim.Adam(leaves, lr=1e-4)
+            t0 = time.time()
+            n = 0
+            while time.time() - t0 < 6.0 or n < 2:
+                copt.zero_grad()
+                O.icfm_flow_matching_loss(lambda tt, y: O.intrinsic_forward(sd, tt, y, cc), cx0, cx1, ct, ce, 0.1).backward()
+                copt.step()
+                n += 1
+            cdt = (time.time() - t0) / n
+            entry["cpu_baseline"] = {"value": Bc / cdt, "unit": "rows/s", "cores": cpu_threads(), "kind": "port",
+                                     "sample": "%d steps of batch %d, oracle loss + torch autograd + Adam, %.1f s" % (n, Bc, cdt * n)}
+        except Exception as e:  # noqa: BLE001
+            entry["cpu_baseline"] = {"error": repr(e)}
+        res.append(entry)
+    except Exception as e:  # noqa: BLE001
+        res.append({"name": "C3_icfm_train", "error": repr(e)})
+    return res
 
 
 def main():
@@ -96,59 +231,52 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--states", type=int, default=N_STATES, help="states per GPU (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--dry", action="store_true", help="CPU rehearsal of the launch path (gloo, stubbed step)")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    device = "cuda:%d" % local
-    torch.cuda.set_device(local)
-
-    from generativerl_preview_amd import engine
-    model = build_model(device)
-    gen = torch.Generator(device=device).manual_seed(1 + rank)
-    states = torch.randn(args.states, 17, device=device, generator=gen)  # this rank's block of states
-    t_span = torch.linspace(0.0, 1.0, N_SOLVER_STEPS + 1)
+    from generativerl_preview_amd import launch
+    if launch.needs_self_launch(args.gpus):   # nothing has touched the GPU yet
+        sys.exit(launch.self_launch(args.gpus))
+    ranks = launch.Ranks(args.gpus, dry=args.dry)
+    rank, world, device = ranks.rank, ranks.world, ranks.device
     rows = args.states * N_CAND
+    t_span = torch.linspace(0.0, 1.0, N_SOLVER_STEPS + 1)
 
-    def step():
-        # QGPO candidate generation: K = 32 actions per state, one fused launch over N*K rows
-        return model.sample(t_span=t_span, batch_size=N_CAND, condition=states)
+    if args.dry:
+        engine = model = None
+        w = torch.randn(64, 64)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        def step():  # stand-in for the HIP launch: a little CPU work, rank-dependent so that MAX differs from local
+            time.sleep(0.005 * (1 + rank))
+            return (torch.randn(N_CAND, args.states, 6) @ torch.eye(6)) + 0.0 * w.sum()
+    else:
+        from generativerl_preview_amd import engine
+        model = build_model(device)
+        gen = torch.Generator(device=device).manual_seed(1 + rank)
+        states = torch.randn(args.states, 17, device=device, generator=gen)  # this rank's block of states
+
+        def step():
+            # QGPO candidate generation: K = 32 actions per state, one fused launch over N*K rows
+            return model.sample(t_span=t_span, batch_size=N_CAND, condition=states)
 
     for _ in range(args.warmup):
         out = step()
-    barrier()
-    engine.KERNEL_EVENTS = []
+    ranks.barrier()
+    if engine is not None:
+        engine.KERNEL_EVENTS = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    events, engine.KERNEL_EVENTS = engine.KERNEL_EVENTS, None
+    ranks.barrier()
+    elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
+    events = []
+    if engine is not None:
+        events, engine.KERNEL_EVENTS = engine.KERNEL_EVENTS, None
     assert out.shape == (N_CAND, args.states, 6) and bool(torch.isfinite(out).all())
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
 
     if rank == 0:
-        kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, len(events))
-        achieved = rows * N_SOLVER_STEPS * FLOP_PER_ACTION_STEP / (kernel_ms * 1e-3) / 1e12
         total_rows = rows * world * args.steps
-        traffic, traffic_src = pmc_traffic(rows)
         res = {
             "metric": "action samples/sec (100-step ODE)",
             "value": total_rows / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
@@ -159,18 +287,26 @@ def main():
                                    "100-step Euler ODE on linspace(0,1,101), linear VP-SDE noise net [512,256,128], "
                                    "obs 17 / act 6, unguided, finals only" % (args.states, N_CAND),
                        "rows_per_gpu": rows, "solver_steps": N_SOLVER_STEPS, "parallelism": "batch-sharded x%d, no collective" % world},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_unit": "bytes per launch",
-                         "traffic_source": traffic_src,
-                         "kernel": "k_sample_bf16", "kernel_ms": kernel_ms,
-                         "algorithmic_flop_per_launch": rows * N_SOLVER_STEPS * FLOP_PER_ACTION_STEP},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(model)
+        if args.dry:
+            res["dry"] = True
+            res["roofline"] = None
+        else:
+            kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, len(events))
+            achieved = rows * N_SOLVER_STEPS * FLOP_PER_ACTION_STEP / (kernel_ms * 1e-3) / 1e12
+            traffic, traffic_src = pmc_traffic(rows)
+            res["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                               "traffic_source": traffic_src,
+                               "kernel": "k_sample_bf16", "kernel_ms": kernel_ms,
+                               "algorithmic_flop_per_launch": rows * N_SOLVER_STEPS * FLOP_PER_ACTION_STEP}
+            if world == 1 and not args.no_cpu_baseline:
+                res["cpu_baseline"] = cpu_baseline(model)
+            if world == 1 and not args.no_secondary:
+                del out
+                res["secondary"] = secondary_results(device, model)
         print(json.dumps(res), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":

@@ -11,17 +11,15 @@
 using namespace grlhip;
 
 namespace grlhip {
-int device_cus() {
-  static int cus = -1;
-  if (cus < 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-      cus = v;
-    else
-      cus = 256;
+int device_cus() {  // CU count of the CURRENT device (cached per device ordinal)
+  static int cus[64] = {0};
+  int dev = 0, v = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cus[dev] <= 0) {
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus[dev] = v;
+    else cus[dev] = 256;
   }
-  return cus;
+  return cus[dev];
 }
 }  // namespace grlhip
 

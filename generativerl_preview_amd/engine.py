@@ -36,7 +36,8 @@ def _f32c(t, name, shape=None):
 class NetPlan:
     """One network description -> plan handle (grlhip_plan_create)."""
 
-    def __init__(self, kind, x_dim, out_dim, cond_dim, t_dim, cond_hidden, t_cond_hidden, hidden):
+    def __init__(self, kind, x_dim, out_dim, cond_dim, t_dim, cond_hidden, t_cond_hidden, hidden, device=None):
+        """`device`: the HIP device the plan's program tables are uploaded to (made current for the call)."""
         d = L.NetDesc()
         d.kind, d.x_dim, d.out_dim, d.cond_dim, d.t_dim = kind, x_dim, out_dim, cond_dim or 0, t_dim
         d.cond_hidden, d.t_cond_hidden, d.n_hidden = cond_hidden or 0, t_cond_hidden or 0, len(hidden)
@@ -47,7 +48,13 @@ class NetPlan:
         self.desc = d
         self.kind, self.x_dim, self.out_dim, self.cond_dim = kind, x_dim, out_dim, cond_dim or 0
         h = ctypes.c_void_p()
-        L.check(L.lib().grlhip_plan_create(ctypes.byref(d), ctypes.byref(h)))
+        device = torch.device(device) if device is not None else None
+        if device is not None and device.type == "cuda":
+            with torch.cuda.device(device):
+                L.check(L.lib().grlhip_plan_create(ctypes.byref(d), ctypes.byref(h)))
+        else:
+            L.check(L.lib().grlhip_plan_create(ctypes.byref(d), ctypes.byref(h)))
+        self.device = device
         self.handle = h
         self._ws = {}
         n = L.lib().grlhip_plan_num_params(h)
@@ -93,6 +100,18 @@ class NetPlan:
             self._ws[key] = ws
         return ws
 
+    def train_workspace(self, rows, device):
+        """Cached workspace of the training / backward entry points (gigabytes at 65 536 rows): grown on demand."""
+        need = L.lib().grlhip_loss_workspace_bytes(self.handle, rows, L.F32)
+        key = (str(device), "train")
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            self._ws.pop(key, None)
+            ws = None
+            ws = torch.empty(max(need, 256), dtype=torch.uint8, device=device)
+            self._ws[key] = ws
+        return ws
+
     def forward(self, packed, t, x, cond, dtype=L.F32):
         rows = x.shape[0]
         dev = x.device
@@ -113,8 +132,7 @@ class NetPlan:
         grad_out = _f32c(grad_out, "grad_out", (rows, self.out_dim))
         flat = torch.zeros(L.lib().grlhip_grad_numel(self.handle), dtype=torch.float32, device=dev) if need_params else None
         gx = torch.empty(rows, self.x_dim, dtype=torch.float32, device=dev) if need_x else None
-        need = L.lib().grlhip_loss_workspace_bytes(self.handle, rows, L.F32)
-        ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+        ws = self.train_workspace(rows, dev)
         with torch.cuda.device(dev):
             L.check(L.lib().grlhip_net_backward(self.handle, _ptr(packed), L.F32, _ptr(t), _ptr(x), _ptr(cond),
                                                 _ptr(grad_out), _ptr(flat), _ptr(gx), rows, _ptr(ws), ws.numel(),
@@ -129,8 +147,7 @@ class NetPlan:
         cond, coef = _f32c(cond, "condition"), _f32c(coef.to(dev), "coef", (n1 - 1, L.COEF_STRIDE))
         flat = torch.zeros(L.lib().grlhip_grad_numel(self.handle), dtype=torch.float32, device=dev)
         gx0 = torch.empty(rows, D, dtype=torch.float32, device=dev)
-        need = L.lib().grlhip_loss_workspace_bytes(self.handle, rows, L.F32)
-        ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+        ws = self.train_workspace(rows, dev)
         with torch.cuda.device(dev):
             L.check(L.lib().grlhip_sample_ode_backward(self.handle, _ptr(packed), L.F32, _ptr(traj), _ptr(cond), _ptr(coef),
                                                        n1 - 1, rows, _ptr(grad_traj), _ptr(gx0), _ptr(flat), _ptr(ws),

@@ -32,9 +32,29 @@ class IntrinsicModel(nn.Module):
         self._plan = None
         self._packed = {}
 
+    # derived HIP state (plan handle, packed images, gradient staging) is never copied or pickled: a deep copy
+    # (target networks) or a checkpoint rebuilds it lazily from the parameters
+    _DERIVED = ("_plan", "_packed", "_flat_grads", "_grad_stage", "_stage_token")
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        for k in self._DERIVED:
+            st.pop(k, None)
+        st["_plan"], st["_packed"] = None, {}
+        return st
+
+    def _device(self):
+        return next(self.model["backbone"].parameters()).device
+
     # ------------------------------------------------------------------ HIP plumbing
     @property
     def plan(self) -> NetPlan:
+        dev = self._device()
+        if self._plan is not None and dev.type == "cuda" and self._plan.device is not None and self._plan.device != dev:
+            # the module moved to another GPU: the plan's program tables and every derived image live on the old one
+            self._plan, self._packed = None, {}
+            for k in ("_flat_grads", "_grad_stage", "_stage_token"):
+                self.__dict__.pop(k, None)
         if self._plan is None:
             te, bb = self.model["t_encoder"], self.model["backbone"]
             if not isinstance(te, GaussianFourierProjectionTimeEncoder) or \
@@ -46,7 +66,7 @@ class IntrinsicModel(nn.Module):
                 d = bb.hip_desc()
                 assert d["t_dim"] == te.embed_dim, "backbone t_dim must equal the t_encoder embed_dim"
                 self._plan = NetPlan(L.NET_RESNET, d["x_dim"], d["out_dim"], d["cond_dim"], d["t_dim"],
-                                     d["cond_hidden"], d["t_cond_hidden"], d["hidden"])
+                                     d["cond_hidden"], d["t_cond_hidden"], d["hidden"], device=dev)
             elif isinstance(bb, ConcatenateMLP):
                 d = bb.hip_desc()
                 # input is cat[t_emb, x, c]; x/c split is fixed at first use (set_io_dims)
@@ -54,7 +74,7 @@ class IntrinsicModel(nn.Module):
                     raise RuntimeError("ConcatenateMLP IntrinsicModel: call set_io_dims(x_dim, cond_dim) first")
                 x_dim, c_dim = self._io_dims
                 assert d["in_dim"] == te.embed_dim + x_dim + c_dim, "ConcatenateMLP input width mismatch"
-                self._plan = NetPlan(L.NET_CONCAT_MLP, x_dim, d["out_dim"], c_dim, te.embed_dim, 0, 0, d["hidden"])
+                self._plan = NetPlan(L.NET_CONCAT_MLP, x_dim, d["out_dim"], c_dim, te.embed_dim, 0, 0, d["hidden"], device=dev)
             else:
                 raise NotImplementedError("no fused kernel for backbone %s" % type(bb).__name__)
         return self._plan

@@ -9,6 +9,7 @@ build x_t, alpha, beta and target with a handful of elementwise device ops, and 
 the network forward+backward in the HIP library (``grlhip_loss_fwd_bwd``), exposing the result to
 autograd so ``loss.backward()`` fills ``.grad`` of the ordinary parameters."""
 import ctypes
+import weakref
 
 import torch
 
@@ -97,17 +98,62 @@ def prepare_icfm(process, x0, x1, t=None, noise=None):
     return t, x_t, torch.ones_like(t), torch.zeros_like(t), process.velocity(t, x0, x1)
 
 
+def _param_grads(model, flat, n_params):
+    """Views of the library's flat gradient, one per parameter in plan order (None where no grad is required)."""
+    plan = model.plan
+    named = model._named()
+    grads = []
+    for i, (name, shape) in enumerate(plan.params):
+        p = named[name]
+        if p.requires_grad and flat is not None:
+            off = L.lib().grlhip_grad_offset(plan.handle, i)
+            grads.append(flat[off:off + p.numel()].view(p.shape))
+        else:
+            grads.append(None)
+    assert len(grads) == n_params
+    return grads
+
+
+class _StageToken:
+    """Lives as long as the autograd node whose backward still needs the staged gradient."""
+    __slots__ = ("__weakref__",)
+
+
+def _stage(model, n, dev):
+    """Zeroed fp32 buffer for this call's own gradient contribution + the token that keeps it reserved.  The
+    buffer is cached on the model and reused once the previous call's autograd node is gone (its backward ran or its
+    graph was dropped); while that node is alive -- two losses of one model summed before one backward -- a fresh
+    buffer is handed out instead."""
+    ref = getattr(model, "_stage_token", None)
+    if ref is not None and ref() is not None:
+        return torch.zeros(n, dtype=torch.float32, device=dev), None
+    st = getattr(model, "_grad_stage", None)
+    if st is None or st.numel() != n or st.device != torch.device(dev):
+        st = torch.empty(n, dtype=torch.float32, device=dev)
+        model._grad_stage = st
+    st.zero_()
+    token = _StageToken()
+    model._stage_token = weakref.ref(token)
+    return st, token
+
+
 class _FusedLoss(torch.autograd.Function):
+    """forward = ONE grlhip_loss_fwd_bwd call (loss and, when a parameter requires grad under an enabled grad mode,
+    the gradient of the mean loss into a staging buffer); backward scales the staged gradient by grad_output.
+    With a FlatGrads buffer attached to the model (distributed.attach_flat_grads) the backward is one fused
+    ``flat += g * staged`` pass into the buffer the parameters' ``.grad`` alias, and autograd receives no
+    per-parameter tensors at all."""
+
     @staticmethod
-    def forward(ctx, model, t, x_t, cond, alpha, beta, target, average, *params):
+    def forward(ctx, model, t, x_t, cond, alpha, beta, target, average, grad_mode, *params):
         plan = model.plan
         B = x_t.shape[0]
         dev = x_t.device
         lib = L.lib()
         loss_rows = torch.empty(B, dtype=torch.float32, device=dev)
         n_grad = lib.grlhip_grad_numel(plan.handle)
-        need_grad = any(p.requires_grad for p in params)
-        flat = torch.zeros(n_grad, dtype=torch.float32, device=dev) if (need_grad and average) else None
+        need_grad = grad_mode and any(p.requires_grad for p in params)
+        flat, ctx.token = _stage(model, n_grad, dev) if (need_grad and average) else (None, None)
         roww = torch.full((B,), 1.0 / B, dtype=torch.float32, device=dev) if flat is not None else None
         _launch(model, t, x_t, cond, alpha, beta, target, roww, loss_rows, flat)
         ctx.model, ctx.average, ctx.flat = model, average, flat
@@ -123,25 +169,27 @@ class _FusedLoss(torch.autograd.Function):
         model = ctx.model
         plan = model.plan
         if ctx.average:
-            flat = ctx.flat * gout
+            flat = ctx.flat
+            scale = gout
         else:
             t, x_t, cond, alpha, beta, target = ctx.saved_tensors
             flat = torch.zeros(L.lib().grlhip_grad_numel(plan.handle), dtype=torch.float32, device=x_t.device)
             scratch = torch.empty(x_t.shape[0], dtype=torch.float32, device=x_t.device)
             _launch(model, t, x_t, cond if ctx.has_cond else None, alpha, beta, target,
                     gout.contiguous().float(), scratch, flat)
-        grads = []
-        named = model._named()
-        names = [n for n, _ in plan.params]
-        for i, (name, shape) in enumerate(plan.params):
-            p = named[name]
-            if p.requires_grad:
-                off = L.lib().grlhip_grad_offset(plan.handle, i)
-                grads.append(flat[off:off + p.numel()].view(p.shape))
+            scale = None
+        none8 = (None,) * 9
+        fg = getattr(model, "_flat_grads", None)
+        if fg is not None and flat is not None:
+            fg.ensure()
+            if scale is None:
+                fg.grads.add_(flat)
             else:
-                grads.append(None)
-        assert len(names) == ctx.n_params
-        return (None, None, None, None, None, None, None, None, *grads)
+                torch.addcmul(fg.grads, flat, scale.reshape(1).expand_as(flat), out=fg.grads)
+            return (*none8, *([None] * ctx.n_params))
+        if flat is not None:
+            flat = flat * scale if scale is not None else flat.clone()
+        return (*none8, *_param_grads(model, flat, ctx.n_params))
 
 
 def _launch(model, t, x_t, cond, alpha, beta, target, roww, loss_rows, flat):
@@ -150,8 +198,7 @@ def _launch(model, t, x_t, cond, alpha, beta, target, roww, loss_rows, flat):
     lib = L.lib()
     t, x_t, cond = _f32c(t, "t", (B,)), _f32c(x_t, "x_t", (B, plan.x_dim)), _f32c(cond, "condition")
     alpha, beta, target = _f32c(alpha, "alpha", (B,)), _f32c(beta, "beta", (B,)), _f32c(target, "target", (B, plan.out_dim))
-    need = lib.grlhip_loss_workspace_bytes(plan.handle, B, L.F32)
-    ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+    ws = plan.train_workspace(B, dev)
     with torch.cuda.device(dev):
         L.check(lib.grlhip_loss_fwd_bwd(plan.handle, _ptr(model.packed(L.F32)), L.F32, _ptr(t), _ptr(x_t), _ptr(cond),
                                         _ptr(alpha), _ptr(beta), _ptr(target), _ptr(roww), _ptr(loss_rows),
@@ -162,7 +209,7 @@ def fused_loss(model, t, x_t, cond, alpha, beta, target, average=True):
     """model: IntrinsicModel.  Returns the scalar mean loss (average=True) or the per-row losses."""
     named = model._named()
     params = [named[n] for n, _ in model.plan.params]
-    return _FusedLoss.apply(model, t, x_t, cond, alpha, beta, target, average, *params)
+    return _FusedLoss.apply(model, t, x_t, cond, alpha, beta, target, average, torch.is_grad_enabled(), *params)
 
 
 class _FusedCepLoss(torch.autograd.Function):
@@ -170,39 +217,34 @@ class _FusedCepLoss(torch.autograd.Function):
     library call (grlhip_cep_loss_fwd_bwd); the mean over groups is returned."""
 
     @staticmethod
-    def forward(ctx, model, t, x_t, cond, logits0, group_size, *params):
+    def forward(ctx, model, t, x_t, cond, logits0, group_size, grad_mode, *params):
         plan = model.plan
         R, dev = x_t.shape[0], x_t.device
         G = R // group_size
         lib = L.lib()
         loss_groups = torch.empty(G, dtype=torch.float32, device=dev)
-        need_grad = any(p.requires_grad for p in params)
-        flat = torch.zeros(lib.grlhip_grad_numel(plan.handle), dtype=torch.float32, device=dev) if need_grad else None
+        need_grad = grad_mode and any(p.requires_grad for p in params)
+        flat, ctx.token = _stage(model, lib.grlhip_grad_numel(plan.handle), dev) if need_grad else (None, None)
         gw = torch.full((G,), 1.0 / G, dtype=torch.float32, device=dev) if need_grad else None
         t, x_t, cond = _f32c(t, "t", (R,)), _f32c(x_t, "x_t", (R, plan.x_dim)), _f32c(cond, "condition")
         logits0 = _f32c(logits0, "logits0", (R,))
-        need = lib.grlhip_loss_workspace_bytes(plan.handle, R, L.F32)
-        ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+        ws = plan.train_workspace(R, dev)
         with torch.cuda.device(dev):
             L.check(lib.grlhip_cep_loss_fwd_bwd(plan.handle, _ptr(model.packed(L.F32)), L.F32, _ptr(t), _ptr(x_t),
                                                 _ptr(cond), _ptr(logits0), group_size, _ptr(gw), _ptr(loss_groups),
                                                 _ptr(flat), R, _ptr(ws), ws.numel(), _stream(dev)))
-        ctx.model, ctx.flat = model, flat
+        ctx.model, ctx.flat, ctx.n_params = model, flat, len(params)
         return loss_groups.mean()
 
     @staticmethod
     def backward(ctx, gout):
-        plan = ctx.model.plan
-        named = ctx.model._named()
-        grads = []
-        for i, (name, shape) in enumerate(plan.params):
-            p = named[name]
-            if p.requires_grad and ctx.flat is not None:
-                off = L.lib().grlhip_grad_offset(plan.handle, i)
-                grads.append((ctx.flat[off:off + p.numel()] * gout).view(p.shape))
-            else:
-                grads.append(None)
-        return (None, None, None, None, None, None, *grads)
+        model, flat = ctx.model, ctx.flat
+        fg = getattr(model, "_flat_grads", None)
+        if fg is not None and flat is not None:
+            fg.ensure()
+            torch.addcmul(fg.grads, flat, gout.reshape(1).expand_as(flat), out=fg.grads)
+            return (*((None,) * 7), *([None] * ctx.n_params))
+        return (*((None,) * 7), *_param_grads(model, None if flat is None else flat * gout, ctx.n_params))
 
 
 def fused_cep_loss(model, t, x_t, cond, logits0, group_size):
@@ -210,4 +252,4 @@ def fused_cep_loss(model, t, x_t, cond, logits0, group_size):
     consecutive support actions; returns -mean_b sum_k softmax(logits0)_bk log_softmax(f(t, x_t, c))_bk."""
     named = model._named()
     params = [named[n] for n, _ in model.plan.params]
-    return _FusedCepLoss.apply(model, t, x_t, cond, logits0, group_size, *params)
+    return _FusedCepLoss.apply(model, t, x_t, cond, logits0, group_size, torch.is_grad_enabled(), *params)

@@ -56,7 +56,8 @@ class QNetwork(nn.Module):
                 raise RuntimeError("QNetwork: call set_io_dims(action_dim, state_dim) first")
             a_dim, s_dim = self._io_dims
             assert d["in_dim"] == a_dim + s_dim, "ConcatenateMLP input width mismatch"
-            self._plan = NetPlan(L.NET_QNET, a_dim, d["out_dim"], s_dim, 0, 0, 0, d["hidden"])
+            self._plan = NetPlan(L.NET_QNET, a_dim, d["out_dim"], s_dim, 0, 0, 0, d["hidden"],
+                                 device=next(self.parameters()).device)
         return self._plan
 
     def _named(self):

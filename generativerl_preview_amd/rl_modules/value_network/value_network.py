@@ -24,6 +24,12 @@ class VNetwork(nn.Module):
         self._plan = None
         self._packed = None
 
+    def __getstate__(self):   # the plan handle and packed image are derived state: never copied or pickled
+        st = dict(self.__dict__)
+        st["_plan"], st["_packed"] = None, None
+        st.pop("_flat_grads", None); st.pop("_grad_stage", None); st.pop("_stage_token", None)
+        return st
+
     @property
     def plan(self) -> NetPlan:
         if self._plan is None:
@@ -32,7 +38,7 @@ class VNetwork(nn.Module):
                 raise NotImplementedError("the fused value-network kernels support a ReLU MultiLayerPerceptron backbone "
                                           "without dropout/layernorm/final activation/scale")
             sizes, out = bb._sizes
-            self._plan = NetPlan(L.NET_QNET, sizes[0], out, 0, 0, 0, 0, sizes[1:])
+            self._plan = NetPlan(L.NET_QNET, sizes[0], out, 0, 0, 0, 0, sizes[1:], device=next(self.parameters()).device)
         return self._plan
 
     def _named(self):

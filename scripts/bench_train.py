@@ -3,7 +3,7 @@
 forward + backward through the fp32 batch engine, ONE flat gradient all-reduce over RCCL (N > 1), Adam --
 batch 65 536 per GPU (weak scaling).  Same contract as bench.py:
 
-    python scripts/bench_train.py --gpus N --steps K --warmup W     (N > 1: torch.distributed.run)
+    python scripts/bench_train.py --gpus N --steps K --warmup W     (N > 1: spawns its ranks, or torch.distributed.run)
 
 One JSON line on rank 0: training rows/s over all ranks, and the fp32-MFMA roofline of the step.
 """
@@ -31,24 +31,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="rows per GPU")
     args = ap.parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    device = "cuda:%d" % local
-    torch.cuda.set_device(local)
+    from generativerl_preview_amd import launch
+    if launch.needs_self_launch(args.gpus):   # nothing has touched the GPU yet
+        sys.exit(launch.self_launch(args.gpus))
+    ranks = launch.Ranks(args.gpus)
+    rank, world, device, dist = ranks.rank, ranks.world, ranks.device, ranks.dist
 
     import golden_lib as gl
     import generativerl_preview_amd as G
-    from generativerl_preview_amd.distributed import allreduce_gradients
+    from generativerl_preview_amd.distributed import attach_flat_grads
     torch.manual_seed(0)  # identical initial weights on every rank
     m = G.IndependentConditionalFlowModel(dict(gl.icfm_cfg(6, [512, 256, 128], 17), device=device)).to(device)
+    fg = attach_flat_grads(m.model)   # .grad of every parameter is a view of ONE flat buffer
     opt = torch.optim.Adam(m.parameters(), lr=1e-4)
     B = args.batch
     gen = torch.Generator(device=device).manual_seed(1 + rank)
@@ -56,33 +50,16 @@ def main():
     cond = torch.randn(B, 17, device=device, generator=gen)
 
     def step():
-        opt.zero_grad(set_to_none=False)
+        fg.zero()
         x0 = torch.randn(B, 6, device=device, generator=gen)
         loss = m.flow_matching_loss(x0, x1, cond)
-        loss.backward()
-        allreduce_gradients(m.parameters())
+        loss.backward()                      # one fused pass into the flat buffer
+        gl_loss = fg.allreduce(B, loss)      # ONE in-place all-reduce (no-op at world 1)
         opt.step()
-        return loss
+        return loss if gl_loss is None else gl_loss
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, loss = ranks.timed(step, args.warmup, args.steps)
     assert bool(torch.isfinite(loss))
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         achieved = B * FLOP_PER_ROW / (ms * 1e-3) / 1e12   # per GPU, whole step (incl. repack, all-reduce, Adam)
@@ -96,10 +73,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_TFLOPS, "traffic": None,
                          "note": "whole step per GPU over wall time; per-kernel split: scripts/profile_train.sh"},
-            "final_loss": float(loss)}), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+            "final_loss": float(loss.detach())}), flush=True)
+    ranks.close()
 
 
 if __name__ == "__main__":

@@ -385,6 +385,35 @@ def test_losses_and_grads_vs_golden(name):
         close(rows, g[pfx + "_loss_rows"], tol=2e-5, what=pfx + " rows", rel=True)
 
 
+def test_flat_gradient_buffer_path_matches_goldens_and_survives_zero_grad():
+    """distributed.attach_flat_grads: the fused loss accumulates straight into ONE flat buffer that every .grad
+    aliases; values equal the goldens, two backward calls accumulate, zero_grad(set_to_none=True) is survived,
+    and under torch.no_grad() no gradient work is done at all."""
+    from generativerl_preview_amd.distributed import attach_flat_grads
+    name = "small_vp_noise"
+    kind, cfg, m = um.build(name, DEV)
+    g = gu.load("model_%s.npz" % name)
+    x, cond = cu(g["x"]), cu(g["cond"])
+    fg = attach_flat_grads(m.model)
+    call = lambda: m.score_matching_loss(x, cond, weighting_scheme="vanilla", t=cu(g["sm_t"]), noise=cu(g["sm_eps"]))  # noqa: E731
+    call().backward()
+    for k, p in m.named_parameters():
+        if k.startswith("model.") and p.requires_grad:
+            assert p.grad.data_ptr() >= fg.flat.data_ptr() and p.grad.data_ptr() < fg.flat.data_ptr() + 4 * fg.n, k
+    _check_grads(m, g, "sm")
+    once = fg.grads.clone()
+    call().backward()                                     # accumulates like autograd does
+    close(fg.grads, 2 * once, tol=1e-6, what="flat grads accumulate", rel=True)
+    torch.optim.SGD(m.parameters(), lr=0.1).zero_grad(set_to_none=True)
+    call().backward()                                     # views re-installed on a zeroed buffer
+    _check_grads(m, g, "sm")
+    fg.zero()
+    with torch.no_grad():
+        loss = call()
+    assert not loss.requires_grad and float(fg.grads.abs().max()) == 0.0
+    assert abs(float(loss) - float(g["sm_loss"])) <= 1e-5 * abs(float(g["sm_loss"]))
+
+
 def test_weighted_rows_backward_and_trainable_fourier():
     """average=False + per-row weights (the GMPO weighted-loss pattern) and a trainable Fourier W
     (swiss-roll tutorial) against torch autograd on the CPU oracle."""
