@@ -15,12 +15,14 @@ using CfgSel = CfgSwiss;
 #endif
 #if B16_GUIDE == 0
 using GuideSel = b16::NoGuide;
+using BodySel = AsmBodyFor<CfgSel>::type;   // unguided kernels run the hand-scheduled assembly body
 #else
 using GuideSel = GuideQgpo;
+using BodySel = b16::NoAsmBody;             // guided kernels: C++ body (net + energy-net gradient)
 #endif
 #define B16_CAT2(a, b, c, d, e, f) a##b##c##d##e##f
 #define B16_CAT(a, b, c, d, e, f) B16_CAT2(a, b, c, d, e, f)
 void B16_CAT(b16_launch_v, B16_VARIANT, _e, B16_EXTRA, _g, B16_GUIDE)(b16::SampleArgs16& a, int blocks, hipStream_t st) {
-  hipLaunchKernelGGL((b16::k_sample_bf16<CfgSel, GuideSel, B16_NSLOT, B16_CF, B16_P, B16_EXTRA>), dim3(blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((b16::k_sample_bf16<CfgSel, GuideSel, B16_NSLOT, B16_CF, B16_P, B16_EXTRA, BodySel>), dim3(blocks), dim3(256), 0, st, a);
 }
 }  // namespace grlhip

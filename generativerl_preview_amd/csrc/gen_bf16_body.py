@@ -1,0 +1,474 @@
+#!/usr/bin/env python3
+"""Generator of the hand-scheduled gfx950 assembly body of the bf16 persistent integrator (engine_bf16.hip.inc).
+
+One solver step of k_sample_bf16 evaluates the whole TemporalSpatialResidualNet for a wave's 32 rows: ~3250
+v_mfma_f32_32x32x16_bf16 whose weight (A) fragments stream through the LDS ring and whose activations never leave
+registers.  With ONE wave per SIMD every instruction of that wave takes a 4-cycle issue slot (8 for v_exp / v_rcp
+and for the MFMA's own issue: MI355X_MICROARCH.md, "vector-instruction ISSUE cost"), so the step cannot run faster
+than max(32 x MFMAs, 4 x issue slots).  The compiler-scheduled C++ body needs 8.3 instructions per MFMA (41.9
+issue cycles; profiles/r02_isa_counts_before.json): accumulators live in AGPRs and every element is copied out with
+v_accvgpr_read, every ordering pin costs an s_nop, every ds_read gets its own s_waitcnt.  This generator emits the
+same arithmetic with ~6.4 instructions per MFMA:
+
+  * register plan (512 per lane): VGPR  v[0:63]    two accumulator buffers (tile n computes into one while tile
+                                                   n-1's epilogue reads the other: MFMA results are VGPR-form, no
+                                                   v_accvgpr_read for the SiLU epilogues)
+                                        v[64:191]  h1 of the current residual block (cvt_pk writes it directly)
+                                        v[192:215] weight-fragment queue (ds_read_b128 runs PF fragments ahead)
+                                        v[216:223] epilogue temporaries
+                                        v[224:255] left to the compiler (operands of the asm statement)
+                                  AGPR  a[0:31] SiLU(t-embedding) fragments, a[32:47] last_block accumulator,
+                                        a[48:175] d0 / later u, d2, up0-out, a[176:239] d1  (MFMA B operands)
+  * epilogues (exp2 -> 1+e -> rcp -> fma, residual, bf16 pack) are software-pipelined element by element and spread
+    evenly over the MFMA gaps of the NEXT tile; the independent chain of a tile (time-MLP / modify_x) is issued
+    first, so that the last epilogue of a layer overlaps the first tile of the next one;
+  * one s_waitcnt per TWO weight fragments, bias tiles are ds_read straight into the accumulator buffer a few gaps
+    ahead, the LDS-DMA refill (4 x buffer_load ... lds) follows the per-chunk barrier as before.
+
+Everything is a pure function of the network shape: `python gen_bf16_body.py <out.inc>` writes one C++ header with
+an inline-asm function per instantiated shape.  Numerics are those of the C++ body (same operation order per
+element, same KD-scaled activation domain)."""
+import os
+import sys
+
+DBG_LO = int(os.environ.get("GEN_LO", "2"))
+DBG_NOP = int(os.environ.get("GEN_NOP", "0"))
+NV = 224            # VGPRs the body owns: v[0:NV-1]
+ACC = (0, 32)       # two accumulator buffers of 32 registers
+HB = 64             # 32 fragments x 4
+QBASE, QSLOTS = 192, 6
+TMP = 216           # 8 temporaries
+A_STE, A_ACCL, A_R1, A_R2 = 0, 32, 48, 176
+
+
+class Cfg:
+    def __init__(self, name, XD, CD, CH, TD, TCH, H0, H1, H2, nslot=4, cf=16):
+        self.name = name
+        self.XD, self.CD, self.CH, self.TD, self.TCH, self.H0, self.H1, self.H2 = XD, CD, CH, TD, TCH, H0, H1, H2
+        self.KS_X = (XD + 15) // 16
+        self.KS_T0, self.KS_T, self.NT_T = (TD + CH) // 16, TCH // 16, TCH // 32
+        self.K0, self.K1, self.K2 = H0 // 16, H1 // 16, H2 // 16
+        self.N0, self.N1, self.N2 = H0 // 32, H1 // 32, H2 // 32
+        assert self.KS_X == 1 and H0 == 2 * H1 and H1 == 2 * H2 and H0 <= 512
+        # bias table offsets (floats), identical to b16::Cfg in engine_bf16.hip.inc
+        self.B_SORT0, self.B_SORT2 = 0, TCH
+        self.B_FIRST = 2 * TCH
+        self.B_LAST = self.B_FIRST + 4 * H0
+        self.B_DOWN0 = self.B_LAST + 32
+        self.B_DOWN1 = self.B_DOWN0 + 4 * H1
+        self.B_MID = self.B_DOWN1 + 4 * H2
+        self.B_UP0 = self.B_MID + 3 * H2
+        self.B_UP1 = self.B_UP0 + 3 * H1
+        self.nslot, self.cf = nslot, cf
+
+
+def vq(b):
+    return "v[%d:%d]" % (b, b + 3)
+
+
+def aq(b):
+    return "a[%d:%d]" % (b, b + 3)
+
+
+class Op:
+    """One epilogue instruction: text, the ops it depends on (index in its list, minimum distance)."""
+    def __init__(self, text, deps=(), trans=False):
+        self.text, self.deps, self.trans = text, list(deps), trans
+
+
+def order_ops(ops):
+    """Greedy in-order list scheduling: keep the given priority order, delay an op until each dependence is
+    at least `mind` instructions old (pads with s_nop only if nothing else can go)."""
+    out, pos, rem = [], {}, list(range(len(ops)))
+    while rem:
+        for i in rem:
+            if all(d in pos and len(out) - pos[d] >= md for d, md in ops[i].deps):
+                pos[i] = len(out)
+                out.append(ops[i])
+                rem.remove(i)
+                break
+        else:
+            out.append(Op("s_nop 0"))
+    return out
+
+
+def silu_epilogue(pa, res_kind, res, out_kind, out, nt_tmp=4):
+    """Epilogue of one 32x32 tile whose pre-activation u = KD * z sits in VGPRs pa[0:16).
+    value[e] = u * rcp(1 + exp2(u)) (+ residual):
+      res_kind 'none'            -> value in pa[e]
+               'acc'  (res = base of the second accumulator, VGPR)  -> v_fmac into res[e]
+               'frag' (res = two AGPR fragment bases holding the bf16 identity residual) -> value in pa[e]
+    out_kind 'v' (out = VGPR base of 8 packed registers) | 'a' (AGPR base of fragment 0, fragment 1)."""
+    ops = []
+    T = [TMP + i for i in range(nt_tmp)]
+    PT = [TMP + 4 + i for i in range(4)]   # two (packed, low) pairs for the identity residual
+    idx = {}
+
+    def add(key, text, deps=(), trans=False):
+        idx[key] = len(ops)
+        ops.append(Op(text, [(idx[k], md) for k, md in deps], trans))
+
+    def stage(e, s):
+        t = T[e % nt_tmp]
+        if s == 0:
+            deps = []
+            if e >= nt_tmp:
+                deps.append((("D", e - nt_tmp), 1))   # temporary reuse
+            add(("A", e), "v_exp_f32_e32 v%d, v%d" % (t, pa + e), deps, True)
+        elif s == 1:
+            add(("B", e), "v_add_f32_e32 v%d, 1.0, v%d" % (t, t), [(("A", e), 3)])
+        elif s == 2:
+            add(("C", e), "v_rcp_f32_e32 v%d, v%d" % (t, t), [(("B", e), 2)], True)
+        else:
+            if res_kind == "none":
+                add(("D", e), "v_mul_f32_e32 v%d, v%d, v%d" % (pa + e, pa + e, t), [(("C", e), 3)])
+            elif res_kind == "acc":
+                add(("D", e), "v_fmac_f32_e32 v%d, v%d, v%d" % (res + e, pa + e, t), [(("C", e), 3)])
+            else:
+                j = e // 2
+                r = PT[2 * (j % 2) + 1] if e % 2 == 0 else PT[2 * (j % 2)]
+                add(("D", e), "v_fma_f32 v%d, v%d, v%d, v%d" % (pa + e, pa + e, t, r),
+                    [(("C", e), 3), (("R1", j) if e % 2 == 0 else ("R2", j), 2)])
+
+    def residual(j):   # packed bf16 pair j (elements 2j, 2j+1) of the identity residual -> two fp32 temporaries
+        frag, reg = res[j // 4], j % 4
+        p, lo = PT[2 * (j % 2)], PT[2 * (j % 2) + 1]
+        deps = [(("D", 2 * (j - 2)), 1), (("D", 2 * (j - 2) + 1), 1)] if j >= 2 else []
+        add(("R0", j), "v_accvgpr_read_b32 v%d, a%d" % (p, frag + reg), deps)
+        add(("R1", j), "v_lshlrev_b32_e32 v%d, 16, v%d" % (lo, p), [(("R0", j), 2)])
+        add(("R2", j), "v_and_b32_e32 v%d, 0xffff0000, v%d" % (p, p), [(("R1", j), 1)])
+
+    def pack(j):
+        val = res if res_kind == "acc" else pa
+        d0, d1 = ("D", 2 * j), ("D", 2 * j + 1)
+        if out_kind == "v":
+            add(("P", j), "v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (out + j, val + 2 * j, val + 2 * j + 1), [(d0, 2), (d1, 2)])
+        else:
+            add(("P", j), "v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (val + 2 * j, val + 2 * j, val + 2 * j + 1), [(d0, 2), (d1, 2)])
+            add(("W", j), "v_accvgpr_write_b32 a%d, v%d" % (out[j // 4] + j % 4, val + 2 * j), [(("P", j), 2)])
+
+    # priority order: element pipeline skewed by one stage per slot (A(e) in slot e + sh, D(e) in slot e + sh + 3);
+    # the residual pair j is unpacked at the end of slot 2j + 2 (after the last user of its temporaries, two slots
+    # before its first use); pack(j) one slot after D(2j + 1)
+    sh = 1 if res_kind == "frag" else 0
+    for k in range(16 + 3 + 4 + sh):
+        for s in range(4):
+            e = k - s - sh
+            if 0 <= e < 16:
+                stage(e, s)
+        if res_kind == "frag" and k >= 2 and k % 2 == 0 and (k - 2) // 2 < 8:
+            residual((k - 2) // 2)
+        jp = k - 5 - sh
+        if jp >= 0 and jp % 2 == 1 and jp // 2 < 8:
+            pack(jp // 2)
+    return order_ops(ops)
+
+
+class Body:
+    def __init__(self, cfg):
+        self.c = cfg
+        self.mf = []        # MFMA list: dict(D, B, chain-first flag, bias seqs to wait for, tile)
+        self.tiles = []     # dict(first, last, buf, ops (epilogue), outputs (register names), kind)
+        self.out = []
+        self.frag_reader = {}
+
+    # ------------------------------------------------------------------ program construction
+    def chain(self, acc, bfrags, tile=None, bias=None):
+        """A run of MFMAs accumulating into `acc` (string of 16 registers), one per B fragment."""
+        for i, b in enumerate(bfrags):
+            self.mf.append(dict(D=acc, B=b, tile=tile, bias=bias if i == 0 else None))
+
+    def new_tile(self, kind):
+        t = dict(idx=len(self.tiles), buf=ACC[len(self.tiles) % 2], first=len(self.mf), kind=kind, ops=[], outs=[],
+                 bias=[])
+        self.tiles.append(t)
+        return t
+
+    def end_tile(self, t, ops, outs):
+        t["last"] = len(self.mf) - 1
+        t["ops"], t["outs"] = ops, outs
+
+    def acc_v(self, base):
+        return "v[%d:%d]" % (base, base + 15)
+
+    def block_h(self, b1, bt, in_frags, ste, nt):
+        """h1[n] = silu(W1 in + b1) + (Wt ste + bt); stream order per tile: time-MLP fragments, then dense1."""
+        for n in range(nt):
+            t = self.new_tile("h")
+            A, Tt = t["buf"], t["buf"] + 16
+            t["bias"] = [(Tt, bt + 32 * n), (A, b1 + 32 * n)]
+            self.chain(self.acc_v(Tt), ste, t, bias=Tt)
+            self.chain(self.acc_v(A), in_frags, t, bias=A)
+            out = HB + 8 * n
+            self.end_tile(t, silu_epilogue(A, "acc", Tt, "v", out), [vq(out), vq(out + 4)])
+
+    def block_o(self, b2, bm, h1, in_frags, nt, modify, out_frags):
+        """out[n] = silu(W2 h1 + b2) + (Wm in + bm | in[n]); stream order per tile: modify_x, then dense2."""
+        for n in range(nt):
+            t = self.new_tile("o")
+            Bq, M = t["buf"], t["buf"] + 16
+            o = (out_frags[2 * n], out_frags[2 * n + 1])
+            if modify:
+                t["bias"] = [(M, bm + 32 * n), (Bq, b2 + 32 * n)]
+                self.chain(self.acc_v(M), in_frags, t, bias=M)
+                self.chain(self.acc_v(Bq), h1, t, bias=Bq)
+                ops = silu_epilogue(Bq, "acc", M, "a", o)
+            else:
+                t["bias"] = [(Bq, b2 + 32 * n)]
+                self.chain(self.acc_v(Bq), h1, t, bias=Bq)
+                ops = silu_epilogue(Bq, "frag", (in_frags_base(in_frags[2 * n]), in_frags_base(in_frags[2 * n + 1])), "a", o)
+            self.end_tile(t, ops, [aq(o[0]), aq(o[1])])
+
+    def build(self):
+        c = self.c
+        hb = [vq(HB + 4 * i) for i in range(32)]
+        ste = [aq(A_STE + 4 * i) for i in range(c.KS_T)]
+        r1 = [A_R1 + 4 * i for i in range(32)]
+        r2 = [A_R2 + 4 * i for i in range(16)]
+        tc = ["%%[tc%d]" % i for i in range(c.KS_T0)]
+        xb = ["%[xb]"]
+        # ---- sort_t.0 -> z (hb[0:KS_T)), sort_t.2 -> ste
+        for n in range(c.NT_T):
+            t = self.new_tile("s")
+            A = t["buf"]
+            t["bias"] = [(A, c.B_SORT0 + 32 * n)]
+            self.chain(self.acc_v(A), tc, t, bias=A)
+            self.end_tile(t, silu_epilogue(A, "none", None, "v", HB + 8 * n), [hb[2 * n], hb[2 * n + 1]])
+        for n in range(c.NT_T):
+            t = self.new_tile("s")
+            A = t["buf"]
+            t["bias"] = [(A, c.B_SORT2 + 32 * n)]
+            self.chain(self.acc_v(A), hb[:c.KS_T], t, bias=A)
+            o = (A_STE + 8 * n, A_STE + 8 * n + 4)
+            self.end_tile(t, silu_epilogue(A, "none", None, "a", o), [aq(o[0]), aq(o[1])])
+        accL = "a[%d:%d]" % (A_ACCL, A_ACCL + 15)
+        H0, H1, H2 = c.H0, c.H1, c.H2
+        d0 = r1[:c.K0]
+        d1 = r2[:c.K1]
+        d2 = r1[c.K1:c.K1 + c.K2]                 # a[A_R1 + 64 ...)
+        u = r1[c.K1 + c.K2:c.K1 + 2 * c.K2]
+        up0 = r1[:c.K1]
+        A = lambda l: [aq(b) for b in l]  # noqa: E731
+        # ---- first block, d0 half of last_block
+        self.block_h(c.B_FIRST, c.B_FIRST + H0, xb, ste, c.N0)
+        self.block_o(c.B_FIRST + 2 * H0, c.B_FIRST + 3 * H0, hb[:c.K0], xb, c.N0, True, d0)
+        self.chain(accL, A(d0))
+        # ---- down blocks
+        self.block_h(c.B_DOWN0, c.B_DOWN0 + H1, A(d0), ste, c.N1)
+        self.block_o(c.B_DOWN0 + 2 * H1, c.B_DOWN0 + 3 * H1, hb[:c.K1], A(d0), c.N1, True, d1)
+        self.block_h(c.B_DOWN1, c.B_DOWN1 + H2, A(d1), ste, c.N2)
+        self.block_o(c.B_DOWN1 + 2 * H2, c.B_DOWN1 + 3 * H2, hb[:c.K2], A(d1), c.N2, True, d2)
+        # ---- middle block (identity residual)
+        self.block_h(c.B_MID, c.B_MID + H2, A(d2), ste, c.N2)
+        self.block_o(c.B_MID + 2 * H2, 0, hb[:c.K2], A(d2), c.N2, False, u)
+        # ---- up blocks over the concatenations (identity residual, in place)
+        cat0 = u + d2
+        self.block_h(c.B_UP0, c.B_UP0 + H1, A(cat0), ste, c.N1)
+        self.block_o(c.B_UP0 + 2 * H1, 0, hb[:c.K1], A(cat0), c.N1, False, up0)
+        cat1 = up0 + d1
+        self.block_h(c.B_UP1, c.B_UP1 + H0, A(cat1), ste, c.N0)
+        self.block_o(c.B_UP1 + 2 * H0, 0, hb[:c.K0], A(cat1), c.N0, False, cat1)
+        self.chain(accL, A(cat1))
+        self.nfrags = len(self.mf)
+
+    # ------------------------------------------------------------------ emission
+    def emit(self, s):
+        self.out.append(s)
+
+    def lds_issue(self):
+        self.lds_seq += 1
+        return self.lds_seq
+
+    def lds_wait(self, seq):
+        if seq > self.lds_done:
+            n = self.lds_seq - seq
+            assert 0 <= n <= 15, n
+            self.emit("s_waitcnt lgkmcnt(%d)" % n)
+            self.lds_done = seq
+
+    def advance(self, chunk):
+        """Ring hand-off at the first read of chunk `chunk`: own pieces landed, barrier, refill the slot freed two
+        chunks ago with chunk + NSLOT - 2 (engine_bf16.hip.inc, Ring)."""
+        c = self.c
+        loads = c.cf // 4
+        src = (chunk + c.nslot - 2) % self.chunks
+        slot = (chunk + c.nslot - 2) % c.nslot
+        self.emit("s_waitcnt vmcnt(%d)" % ((c.nslot - 3) * loads))
+        self.emit("s_barrier")
+        self.emit("s_mov_b32 %%[soff], 0x%x" % (src * c.cf * 1024))
+        self.emit("s_add_u32 m0, %%[ldsw], 0x%x" % (slot * c.cf * 1024))
+        self.emit("s_nop 0")
+        for p in range(loads):
+            off = " offset:%d" % (p * 1024) if p else ""
+            self.emit("buffer_load_dwordx4 %%[voff], %%[rsrc], %%[soff] offen%s lds" % off)
+
+    def frag_read(self, n):
+        """ds_read of weight fragment n into its queue slot (+ the ring hand-off when it opens a chunk)."""
+        c = self.c
+        if n % c.cf == 0:
+            self.advance(n // c.cf)
+        pos = n % (c.cf * c.nslot)
+        self.emit("ds_read_b128 %s, %%[rd] offset:%d" % (vq(QBASE + 4 * (n % QSLOTS)), pos * 1024))
+        self.frag_seq[n] = self.lds_issue()
+
+    def generate(self):
+        c = self.c
+        self.build()
+        nf = self.nfrags
+        used = (nf + c.cf - 1) // c.cf
+        self.chunks = (used + c.nslot - 1) // c.nslot * c.nslot
+        self.lds_seq = self.lds_done = 0
+        self.frag_seq = {}
+        PF = QSLOTS
+        def consumer(name, after):   # first MFMA reading an output fragment AFTER it is produced
+            for g in range(after + 1, nf):
+                if self.mf[g]["B"] == name:
+                    return g
+            return nf + 8
+        # Epilogue window of tile t: gaps [lo, hi).  lo: two MFMAs after the tile's last one (its results are final
+        # and past the MFMA -> VALU read hazard).  hi: before the first MFMA that consumes an output fragment, and
+        # before the bias tiles of tile t+2 are read into the accumulator buffer this epilogue still reads.
+        nt = len(self.tiles)
+        for t in self.tiles:
+            ln = t["last"] - t["first"] + 1
+            t["lead"] = 5 if ln >= 16 else 3
+        self.tiles[0]["bias_gap"] = -1
+        if nt > 1:
+            self.tiles[1]["bias_gap"] = max(self.tiles[1]["first"] - self.tiles[1]["lead"], -1)
+        valu_at, bias_at, forced = {}, {}, {}
+        for t in self.tiles:
+            lo = t["last"] + DBG_LO
+            cidx = min(consumer(o, t["last"]) for o in t["outs"])
+            serial = cidx - 1 <= lo      # the next MFMAs consume this tile's output at once: no gaps to hide in
+            hi = cidx if serial else cidx - 1
+            if t["idx"] + 1 < nt and not serial:
+                # windows must not overlap: consecutive epilogues share the temporaries
+                hi = min(hi, max(self.tiles[t["idx"] + 1]["last"] + DBG_LO, lo + 1))
+            if t["idx"] + 2 < nt:
+                t2 = self.tiles[t["idx"] + 2]
+                cap = t2["first"] - 1
+                assert cap >= hi if serial else cap > lo, (t["idx"], lo, hi, cap)
+                if not serial:
+                    hi = min(hi, cap, max(t2["first"] - t2["lead"], lo + 1))
+                t2["bias_gap"] = max(t2["first"] - t2["lead"], hi)
+                assert hi <= t2["bias_gap"] <= t2["first"] - 1, (t["idx"], hi, t2["bias_gap"], t2["first"])
+            ops = t["ops"]
+            if serial:
+                # results of the tile's last MFMA must be final before the first VALU read (MFMA -> VALU hazard is
+                # not interlocked): idle for two MFMA lengths, run the whole epilogue, then the consumer
+                forced[cidx] = [Op("s_nop 15"), Op("s_nop 15")] + ops + [Op("s_nop 1")]
+            else:
+                if DBG_NOP:
+                    ops = [Op("s_nop 15")] * DBG_NOP + ops
+                for i, op in enumerate(ops):
+                    valu_at.setdefault(lo + i * (hi - lo) // len(ops), []).append(op)
+            t["window"] = (lo, hi)
+        for t in self.tiles:
+            bias_at.setdefault(t["bias_gap"], []).extend(t["bias"])
+        # ---- prologue: last_block bias into its accumulator, first biases, queue priming
+        for q in range(4):
+            self.emit("ds_read_b128 %s, %%[bias] offset:%d" % (aq(A_ACCL + 4 * q), (c.B_LAST + 8 * q) * 4))
+            accl_seq = self.lds_issue()
+        bias_seq = {}
+
+        def bias_reads(gap):
+            for dst, off in bias_at.get(gap, []):
+                for q in range(4):
+                    self.emit("ds_read_b128 %s, %%[bias] offset:%d" % (vq(dst + 4 * q), (off + 8 * q) * 4))
+                    s = self.lds_issue()
+                bias_seq[(gap, dst)] = s
+        bias_reads(-1)
+        for n in range(min(PF, nf)):
+            self.frag_read(n)
+        for g, m in enumerate(self.mf):
+            for op in forced.get(g, []):
+                self.emit(op.text)
+            # operands ready?
+            need = self.frag_seq[g]
+            if g + 1 < nf and (g + 1) in self.frag_seq and g % 2 == 0:
+                need = max(need, self.frag_seq[g + 1])        # one wait per two fragments
+            if m["bias"] is not None:
+                need = max(need, bias_seq[(m["tile"]["bias_gap"], m["bias"])])
+            if m["D"].startswith("a[") and not getattr(self, "_accl_ready", False):
+                need = max(need, accl_seq)
+                self._accl_ready = True
+            self.lds_wait(need)
+            self.emit("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (m["D"], vq(QBASE + 4 * (g % QSLOTS)), m["B"], m["D"]))
+            if g + PF < nf:
+                self.frag_read(g + PF)
+            bias_reads(g)
+            for op in valu_at.get(g, []):
+                self.emit(op.text)
+        # epilogue ops scheduled past the last MFMA (none expected) and the padding chunks of the ring
+        for g in sorted(k for k in valu_at if k >= nf):
+            for op in valu_at[g]:
+                self.emit(op.text)
+        for ch in range(used, self.chunks):
+            self.advance(ch)
+        self.emit("s_waitcnt lgkmcnt(0)")
+        self.emit("s_nop 15")
+        self.emit("s_nop 7")
+        for i in range(8):
+            self.emit("v_accvgpr_read_b32 %%[o%d], a%d" % (i, A_ACCL + i))
+        return self.out
+
+
+def in_frags_base(name):
+    assert name.startswith("a["), name
+    return int(name[2:name.index(":")])
+
+
+def function_text(cfg):
+    b = Body(cfg)
+    lines = b.generate()
+    cnt = {}
+    for l in lines:
+        k = l.split()[0]
+        cnt[k] = cnt.get(k, 0) + 1
+    ntc = cfg.KS_T0
+    o = []
+    o.append("// ---- %s: %d fragments per step, %d instructions (%s)" % (
+        cfg.name, b.nfrags, len(lines), ", ".join("%s %d" % kv for kv in sorted(cnt.items(), key=lambda kv: -kv[1])[:12])))
+    o.append("struct AsmBody_%s {" % cfg.name)
+    o.append("  static constexpr bool ON = true;")
+    o.append("  static constexpr int FRAGS = %d, NSLOT = %d, CF = %d, KS_T0 = %d, INSTRUCTIONS = %d;" % (
+        b.nfrags, cfg.nslot, cfg.cf, ntc, len(lines)))
+    o.append("  static __device__ __forceinline__ void run(const bf16x8* tc, const bf16x8& xb, uint32_t voff, uint32_t rd, "
+             "uint32_t bias, i32x4 rsrc, uint32_t ldsw, float* o) {")
+    o.append("    uint32_t soff;")
+    o.append("    asm volatile(")
+    for l in lines:
+        o.append('      "%s\\n\\t"' % l)
+    outs = ", ".join('[o%d] "=v"(o[%d])' % (i, i) for i in range(8)) + ', [soff] "=&s"(soff)'
+    ins = ", ".join('[tc%d] "v"(tc[%d])' % (i, i) for i in range(ntc))
+    ins += ', [xb] "v"(xb), [voff] "v"(voff), [rd] "v"(rd), [bias] "v"(bias), [rsrc] "s"(rsrc), [ldsw] "s"(ldsw)'
+    clob = ['"memory"', '"scc"']
+    clob += ['"v%d"' % i for i in range(NV)]
+    clob += ['"a%d"' % i for i in range(256)]
+    o.append("      : %s" % outs)
+    o.append("      : %s" % ins)
+    o.append("      : %s);" % ", ".join(clob))
+    o.append("  }")
+    o.append("};")
+    return "\n".join(o), cnt, len(lines), b
+
+
+CONFIGS = [
+    Cfg("cond_6_17", 6, 17, 32, 32, 128, 512, 256, 128),
+    Cfg("uncond_2", 2, 0, 0, 32, 32, 512, 256, 128),
+]
+
+if __name__ == "__main__":
+    out = sys.argv[1]
+    parts = ["// GENERATED by gen_bf16_body.py -- do not edit.  See that file for the design.", "#pragma once",
+             "namespace grlhip {", "namespace b16 {", "typedef int i32x4 __attribute__((ext_vector_type(4)));"]
+    for cfg in CONFIGS:
+        text, cnt, n, b = function_text(cfg)
+        parts.append(text)
+        mf = cnt.get("v_mfma_f32_32x32x16_bf16", 1)
+        trans = cnt.get("v_exp_f32_e32", 0) + cnt.get("v_rcp_f32_e32", 0)
+        sys.stderr.write("%s: %d MFMA, %d instructions (%.2f per MFMA), issue bound %.1f cycles per MFMA\n" % (
+            cfg.name, mf, n, n / mf, 4.0 * (n + trans + mf) / mf))
+    parts += ["}  // namespace b16", "}  // namespace grlhip", ""]
+    with open(out, "w") as f:
+        f.write("\n".join(parts))
