@@ -3,6 +3,9 @@
 // Built with -DB16_VARIANT=0|1 -DB16_EXTRA=0|1|2 (kernel MODE) -DB16_GUIDE=0|1.
 #include <hip/hip_runtime.h>
 
+#if B16_GUIDE == 0
+#define B16_ASM_BODY 1   // unguided kernels run the generated assembly body
+#endif
 #include "plan.hpp"
 #include "engine_bf16.hip.inc"
 #include "engine_bf16_variants.hpp"

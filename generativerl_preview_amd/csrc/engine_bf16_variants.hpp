@@ -9,9 +9,11 @@ using GuideQgpo = b16::GuideCfg<32, 256, 256>;                // QGPO energy net
 #define B16_CF_V 16
 #define B16_P_V 8
 #endif
+#if defined(B16_ASM_BODY)
 // the generated assembly body of each sampler shape (engine_bf16_body_gen.inc)
 template <class C> struct AsmBodyFor;
 template <> struct AsmBodyFor<CfgQgpo> { using type = b16::AsmBody_cond_6_17; };
 template <> struct AsmBodyFor<CfgSwiss> { using type = b16::AsmBody_uncond_2; };
+#endif
 constexpr int B16_NSLOT = B16_NSLOT_V, B16_CF = B16_CF_V, B16_P = B16_P_V;  // ring slots, fragments per chunk, register prefetch depth
 }  // namespace grlhip

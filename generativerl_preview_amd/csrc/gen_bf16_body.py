@@ -31,12 +31,17 @@ element, same KD-scaled activation domain)."""
 import os
 import sys
 
+# ---- knobs (environment): the defaults are the shipped schedule; GEN_X are timing experiments with WRONG results
 DBG_LO = int(os.environ.get("GEN_LO", "2"))
 DBG_NOP = int(os.environ.get("GEN_NOP", "0"))
+X = set(filter(None, os.environ.get("GEN_X", "").split(",")))   # novalu, nodma, nobarrier, nofrag, nowait, nowaitv
+SPREAD = int(os.environ.get("GEN_SPREAD", "0"))  # > 0: one LDS-DMA piece every SPREAD MFMAs instead of all after the barrier
+SKEW = int(os.environ.get("GEN_SKEW", "0"))      # > 0: after every ring hand-off wave w idles w * SKEW wait states
 NV = 224            # VGPRs the body owns: v[0:NV-1]
 ACC = (0, 32)       # two accumulator buffers of 32 registers
 HB = 64             # 32 fragments x 4
-QBASE, QSLOTS = 192, 6
+QBASE = 192
+QSLOTS = int(os.environ.get("GEN_PF", "6"))   # weight-fragment queue depth: 6 VGPR slots + up to 4 AGPR slots (a[240:255])
 TMP = 216           # 8 temporaries
 A_STE, A_ACCL, A_R1, A_R2 = 0, 32, 48, 176
 
@@ -68,6 +73,13 @@ def vq(b):
 
 def aq(b):
     return "a[%d:%d]" % (b, b + 3)
+
+
+def qslot(n):
+    """Register quad of weight-queue slot n % QSLOTS."""
+    k = n % QSLOTS
+    assert QSLOTS <= 10
+    return vq(QBASE + 4 * k) if k < 6 else aq(240 + 4 * (k - 6))
 
 
 class Op:
@@ -282,8 +294,11 @@ class Body:
     def lds_wait(self, seq):
         if seq > self.lds_done:
             n = self.lds_seq - seq
-            assert 0 <= n <= 15, n
-            self.emit("s_waitcnt lgkmcnt(%d)" % n)
+            assert n >= 0
+            # the counter has 4 bits: the hardware never lets more than 15 LGKM operations be outstanding, so a
+            # target with >= 15 younger operations is complete by construction
+            if "nowait" not in X and n < 15:
+                self.emit("s_waitcnt lgkmcnt(%d)" % n)
             self.lds_done = seq
 
     def advance(self, chunk):
@@ -293,14 +308,45 @@ class Body:
         loads = c.cf // 4
         src = (chunk + c.nslot - 2) % self.chunks
         slot = (chunk + c.nslot - 2) % c.nslot
-        self.emit("s_waitcnt vmcnt(%d)" % ((c.nslot - 3) * loads))
-        self.emit("s_barrier")
+        if "nowaitv" not in X:
+            self.emit("s_waitcnt vmcnt(%d)" % ((c.nslot - 3) * loads))
+        if "nobarrier" not in X:
+            self.emit("s_barrier")
+        if SKEW:
+            # stagger the waves: they share ONE vector-memory path per CU and every LDS-DMA piece holds its wave for
+            # the ~16 cycles the path needs for 1 KiB; issued by four waves at the same moment the pieces queue up.
+            self.lbl = getattr(self, "lbl", 0) + 1
+            for w in (1, 2, 3):
+                self.emit("s_cmp_lt_u32 %%[wid], %d" % w)
+                self.emit("s_cbranch_scc1 .Lskew%d_%%=" % self.lbl)
+                self.emit("s_nop %d" % (SKEW - 1))
+            self.emit(".Lskew%d_%%=:" % self.lbl)
+        if "nodma" in X:
+            return
         self.emit("s_mov_b32 %%[soff], 0x%x" % (src * c.cf * 1024))
         self.emit("s_add_u32 m0, %%[ldsw], 0x%x" % (slot * c.cf * 1024))
+        if SPREAD:
+            # m0 / soff stay valid until the next hand-off; the pieces are drained by dma_tick()
+            assert not getattr(self, "dma_pending", []), "previous chunk's pieces not issued yet"
+            self.dma_pending = [p for p in range(loads)]
+            self.dma_count = 0
+            return
         self.emit("s_nop 0")
         for p in range(loads):
             off = " offset:%d" % (p * 1024) if p else ""
             self.emit("buffer_load_dwordx4 %%[voff], %%[rsrc], %%[soff] offen%s lds" % off)
+
+    def dma_tick(self, flush=False):
+        if not SPREAD:
+            return
+        pend = getattr(self, "dma_pending", [])
+        self.dma_count = getattr(self, "dma_count", 0) + 1
+        while pend and (flush or self.dma_count % SPREAD == 0):
+            p = pend.pop(0)
+            off = " offset:%d" % (p * 1024) if p else ""
+            self.emit("buffer_load_dwordx4 %%[voff], %%[rsrc], %%[soff] offen%s lds" % off)
+            if not flush:
+                break
 
     def frag_read(self, n):
         """ds_read of weight fragment n into its queue slot (+ the ring hand-off when it opens a chunk)."""
@@ -308,7 +354,10 @@ class Body:
         if n % c.cf == 0:
             self.advance(n // c.cf)
         pos = n % (c.cf * c.nslot)
-        self.emit("ds_read_b128 %s, %%[rd] offset:%d" % (vq(QBASE + 4 * (n % QSLOTS)), pos * 1024))
+        if "nofrag" in X:
+            self.frag_seq[n] = self.lds_seq
+            return
+        self.emit("ds_read_b128 %s, %%[rd] offset:%d" % (qslot(n), pos * 1024))
         self.frag_seq[n] = self.lds_issue()
 
     def generate(self):
@@ -393,18 +442,24 @@ class Body:
                 need = max(need, accl_seq)
                 self._accl_ready = True
             self.lds_wait(need)
-            self.emit("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (m["D"], vq(QBASE + 4 * (g % QSLOTS)), m["B"], m["D"]))
+            self.emit("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (m["D"], qslot(g), m["B"], m["D"]))
             if g + PF < nf:
+                if (g + PF) % c.cf == 0:
+                    self.dma_tick(flush=True)     # pieces of the previous chunk must be issued before the next hand-off
                 self.frag_read(g + PF)
+            self.dma_tick()
             bias_reads(g)
             for op in valu_at.get(g, []):
-                self.emit(op.text)
+                if "novalu" not in X:
+                    self.emit(op.text)
         # epilogue ops scheduled past the last MFMA (none expected) and the padding chunks of the ring
         for g in sorted(k for k in valu_at if k >= nf):
             for op in valu_at[g]:
                 self.emit(op.text)
         for ch in range(used, self.chunks):
+            self.dma_tick(flush=True)
             self.advance(ch)
+        self.dma_tick(flush=True)
         self.emit("s_waitcnt lgkmcnt(0)")
         self.emit("s_nop 15")
         self.emit("s_nop 7")
@@ -434,14 +489,14 @@ def function_text(cfg):
     o.append("  static constexpr int FRAGS = %d, NSLOT = %d, CF = %d, KS_T0 = %d, INSTRUCTIONS = %d;" % (
         b.nfrags, cfg.nslot, cfg.cf, ntc, len(lines)))
     o.append("  static __device__ __forceinline__ void run(const bf16x8* tc, const bf16x8& xb, uint32_t voff, uint32_t rd, "
-             "uint32_t bias, i32x4 rsrc, uint32_t ldsw, float* o) {")
+             "uint32_t bias, i32x4 rsrc, uint32_t ldsw, uint32_t wid, float* o) {")
     o.append("    uint32_t soff;")
     o.append("    asm volatile(")
     for l in lines:
         o.append('      "%s\\n\\t"' % l)
     outs = ", ".join('[o%d] "=v"(o[%d])' % (i, i) for i in range(8)) + ', [soff] "=&s"(soff)'
     ins = ", ".join('[tc%d] "v"(tc[%d])' % (i, i) for i in range(ntc))
-    ins += ', [xb] "v"(xb), [voff] "v"(voff), [rd] "v"(rd), [bias] "v"(bias), [rsrc] "s"(rsrc), [ldsw] "s"(ldsw)'
+    ins += ', [xb] "v"(xb), [voff] "v"(voff), [rd] "v"(rd), [bias] "v"(bias), [rsrc] "s"(rsrc), [ldsw] "s"(ldsw), [wid] "s"(wid)'
     clob = ['"memory"', '"scc"']
     clob += ['"v%d"' % i for i in range(NV)]
     clob += ['"a%d"' % i for i in range(256)]
