@@ -26,6 +26,6 @@ using BodySel = b16::NoAsmBody;             // guided kernels: C++ body (net + e
 #define B16_CAT2(a, b, c, d, e, f) a##b##c##d##e##f
 #define B16_CAT(a, b, c, d, e, f) B16_CAT2(a, b, c, d, e, f)
 void B16_CAT(b16_launch_v, B16_VARIANT, _e, B16_EXTRA, _g, B16_GUIDE)(b16::SampleArgs16& a, int blocks, hipStream_t st) {
-  hipLaunchKernelGGL((b16::k_sample_bf16<CfgSel, GuideSel, B16_NSLOT, B16_CF, B16_P, B16_EXTRA, BodySel>), dim3(blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((b16::k_sample_bf16<CfgSel, GuideSel, (B16_GUIDE == 0 ? B16_NSLOT_ASM : B16_NSLOT), (B16_GUIDE == 0 ? B16_CF_ASM : B16_CF), B16_P, B16_EXTRA, BodySel>), dim3(blocks), dim3(256), 0, st, a);
 }
 }  // namespace grlhip

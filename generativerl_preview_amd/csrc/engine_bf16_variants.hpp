@@ -16,4 +16,15 @@ template <> struct AsmBodyFor<CfgQgpo> { using type = b16::AsmBody_cond_6_17; };
 template <> struct AsmBodyFor<CfgSwiss> { using type = b16::AsmBody_uncond_2; };
 #endif
 constexpr int B16_NSLOT = B16_NSLOT_V, B16_CF = B16_CF_V, B16_P = B16_P_V;  // ring slots, fragments per chunk, register prefetch depth
+// The assembly-body kernels need no LDS parking and use the space for a deeper ring: the weight stream is latency
+// bound (Little's law: chunks in flight x 16 KiB per ~1 us of L2 latency under load), not bandwidth bound.
+#ifndef B16_NSLOT_ASM_V
+#define B16_NSLOT_ASM_V 8
+#endif
+#ifndef B16_CF_ASM_V
+#define B16_CF_ASM_V B16_CF_V
+#endif
+constexpr int B16_NSLOT_ASM = B16_NSLOT_ASM_V, B16_CF_ASM = B16_CF_ASM_V;
+// the packed stream is padded to a whole number of chunk groups of the deepest ring
+constexpr int B16_NSLOT_LAYOUT = B16_NSLOT_ASM > B16_NSLOT ? B16_NSLOT_ASM : B16_NSLOT;
 }  // namespace grlhip

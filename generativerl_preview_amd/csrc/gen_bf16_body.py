@@ -35,19 +35,23 @@ import sys
 DBG_LO = int(os.environ.get("GEN_LO", "2"))
 DBG_NOP = int(os.environ.get("GEN_NOP", "0"))
 X = set(filter(None, os.environ.get("GEN_X", "").split(",")))   # novalu, nodma, nobarrier, nofrag, nowait, nowaitv
-SPREAD = int(os.environ.get("GEN_SPREAD", "0"))  # > 0: one LDS-DMA piece every SPREAD MFMAs instead of all after the barrier
+SPREAD = int(os.environ.get("GEN_SPREAD", "2"))  # > 0: one LDS-DMA piece every SPREAD MFMAs instead of all after the barrier
+WAITB = int(os.environ.get("GEN_WAITB", "4"))    # one s_waitcnt per WAITB weight fragments
+BSPREAD = int(os.environ.get("GEN_BSPREAD", "2"))  # > 0: bias ds_reads spread, BSPREAD per gap
 SKEW = int(os.environ.get("GEN_SKEW", "0"))      # > 0: after every ring hand-off wave w idles w * SKEW wait states
 NV = 224            # VGPRs the body owns: v[0:NV-1]
 ACC = (0, 32)       # two accumulator buffers of 32 registers
 HB = 64             # 32 fragments x 4
 QBASE = 192
-QSLOTS = int(os.environ.get("GEN_PF", "6"))   # weight-fragment queue depth: 6 VGPR slots + up to 4 AGPR slots (a[240:255])
+QSLOTS = int(os.environ.get("GEN_PF", "8"))   # weight-fragment queue depth: 6 VGPR slots + up to 4 AGPR slots (a[240:255])
 TMP = 216           # 8 temporaries
 A_STE, A_ACCL, A_R1, A_R2 = 0, 32, 48, 176
 
 
 class Cfg:
-    def __init__(self, name, XD, CD, CH, TD, TCH, H0, H1, H2, nslot=4, cf=16):
+    def __init__(self, name, XD, CD, CH, TD, TCH, H0, H1, H2, nslot=None, cf=None):
+        nslot = nslot or int(os.environ.get("GEN_NSLOT", "8"))
+        cf = cf or int(os.environ.get("GEN_CF", "16"))
         self.name = name
         self.XD, self.CD, self.CH, self.TD, self.TCH, self.H0, self.H1, self.H2 = XD, CD, CH, TD, TCH, H0, H1, H2
         self.KS_X = (XD + 15) // 16
@@ -333,8 +337,17 @@ class Body:
             return
         self.emit("s_nop 0")
         for p in range(loads):
-            off = " offset:%d" % (p * 1024) if p else ""
-            self.emit("buffer_load_dwordx4 %%[voff], %%[rsrc], %%[soff] offen%s lds" % off)
+            self.piece(p)
+
+    def piece(self, p):
+        """One 1 KiB LDS-DMA piece of the current chunk.  The immediate offset has 12 bits: every fourth piece steps
+        the source offset and the LDS destination (m0) by 4 KiB."""
+        if p and p % 4 == 0:
+            self.emit("s_add_u32 %[soff], %[soff], 0x1000")
+            self.emit("s_add_u32 m0, m0, 0x1000")
+            self.emit("s_nop 0")
+        off = " offset:%d" % ((p % 4) * 1024) if p % 4 else ""
+        self.emit("buffer_load_dwordx4 %%[voff], %%[rsrc], %%[soff] offen%s lds" % off)
 
     def dma_tick(self, flush=False):
         if not SPREAD:
@@ -342,9 +355,7 @@ class Body:
         pend = getattr(self, "dma_pending", [])
         self.dma_count = getattr(self, "dma_count", 0) + 1
         while pend and (flush or self.dma_count % SPREAD == 0):
-            p = pend.pop(0)
-            off = " offset:%d" % (p * 1024) if p else ""
-            self.emit("buffer_load_dwordx4 %%[voff], %%[rsrc], %%[soff] offen%s lds" % off)
+            self.piece(pend.pop(0))
             if not flush:
                 break
 
@@ -357,7 +368,8 @@ class Body:
         if "nofrag" in X:
             self.frag_seq[n] = self.lds_seq
             return
-        self.emit("ds_read_b128 %s, %%[rd] offset:%d" % (qslot(n), pos * 1024))
+        base = "%[rd]" if pos < 64 else "%[rd2]"      # 16-bit immediate: second base register for the upper 64 KiB
+        self.emit("ds_read_b128 %s, %s offset:%d" % (qslot(n), base, (pos % 64) * 1024))
         self.frag_seq[n] = self.lds_issue()
 
     def generate(self):
@@ -420,12 +432,17 @@ class Body:
             accl_seq = self.lds_issue()
         bias_seq = {}
 
+        bias_queue = []
+
         def bias_reads(gap):
             for dst, off in bias_at.get(gap, []):
                 for q in range(4):
-                    self.emit("ds_read_b128 %s, %%[bias] offset:%d" % (vq(dst + 4 * q), (off + 8 * q) * 4))
-                    s = self.lds_issue()
-                bias_seq[(gap, dst)] = s
+                    bias_queue.append((gap, dst, q, off))
+            n = len(bias_queue) if (not BSPREAD or gap < 0) else min(BSPREAD, len(bias_queue))
+            for _ in range(n):
+                bgap, dst, q, off = bias_queue.pop(0)
+                self.emit("ds_read_b128 %s, %%[bias] offset:%d" % (vq(dst + 4 * q), (off + 8 * q) * 4))
+                bias_seq[(bgap, dst)] = self.lds_issue()
         bias_reads(-1)
         for n in range(min(PF, nf)):
             self.frag_read(n)
@@ -434,10 +451,17 @@ class Body:
                 self.emit(op.text)
             # operands ready?
             need = self.frag_seq[g]
-            if g + 1 < nf and (g + 1) in self.frag_seq and g % 2 == 0:
-                need = max(need, self.frag_seq[g + 1])        # one wait per two fragments
+            if g % WAITB == 0:                                   # one wait per WAITB fragments
+                for k in range(1, WAITB):
+                    if (g + k) in self.frag_seq:
+                        need = max(need, self.frag_seq[g + k])
             if m["bias"] is not None:
-                need = max(need, bias_seq[(m["tile"]["bias_gap"], m["bias"])])
+                key = (m["tile"]["bias_gap"], m["bias"])
+                while any(b[0] == key[0] and b[1] == key[1] for b in bias_queue):   # still queued: issue them now
+                    bgap, dst, q, off = bias_queue.pop(0)
+                    self.emit("ds_read_b128 %s, %%[bias] offset:%d" % (vq(dst + 4 * q), (off + 8 * q) * 4))
+                    bias_seq[(bgap, dst)] = self.lds_issue()
+                need = max(need, bias_seq[key])
             if m["D"].startswith("a[") and not getattr(self, "_accl_ready", False):
                 need = max(need, accl_seq)
                 self._accl_ready = True
@@ -489,14 +513,14 @@ def function_text(cfg):
     o.append("  static constexpr int FRAGS = %d, NSLOT = %d, CF = %d, KS_T0 = %d, INSTRUCTIONS = %d;" % (
         b.nfrags, cfg.nslot, cfg.cf, ntc, len(lines)))
     o.append("  static __device__ __forceinline__ void run(const bf16x8* tc, const bf16x8& xb, uint32_t voff, uint32_t rd, "
-             "uint32_t bias, i32x4 rsrc, uint32_t ldsw, uint32_t wid, float* o) {")
+             "uint32_t rd2, uint32_t bias, i32x4 rsrc, uint32_t ldsw, uint32_t wid, float* o) {")
     o.append("    uint32_t soff;")
     o.append("    asm volatile(")
     for l in lines:
         o.append('      "%s\\n\\t"' % l)
     outs = ", ".join('[o%d] "=v"(o[%d])' % (i, i) for i in range(8)) + ', [soff] "=&s"(soff)'
     ins = ", ".join('[tc%d] "v"(tc[%d])' % (i, i) for i in range(ntc))
-    ins += ', [xb] "v"(xb), [voff] "v"(voff), [rd] "v"(rd), [bias] "v"(bias), [rsrc] "s"(rsrc), [ldsw] "s"(ldsw), [wid] "s"(wid)'
+    ins += ', [xb] "v"(xb), [voff] "v"(voff), [rd] "v"(rd), [rd2] "v"(rd2), [bias] "v"(bias), [rsrc] "s"(rsrc), [ldsw] "s"(ldsw), [wid] "s"(wid)'
     clob = ['"memory"', '"scc"']
     clob += ['"v%d"' % i for i in range(NV)]
     clob += ['"a%d"' % i for i in range(256)]

@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 300 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread -p no:cacheprovider -k "bf16 or static or dpm" 2>&1 | tail -3
-timeout -k 10 400 python -u scripts/xtime.py generativerl_preview_amd/lib_rot.so generativerl_preview_amd/lib_base.so 2>&1 | grep -v amdgpu.ids
+mkdir -p gpurun_out; rm -f gpurun_out/parity_errors.log
+timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread -p no:cacheprovider > gpurun_out/gpu_tests_a.log 2>&1; tail -3 gpurun_out/gpu_tests_a.log
+timeout -k 10 300 python -u scripts/quick_bf16.py 2>&1 | grep -v amdgpu.ids | tail -3
