@@ -35,7 +35,7 @@ import sys
 DBG_LO = int(os.environ.get("GEN_LO", "2"))
 DBG_NOP = int(os.environ.get("GEN_NOP", "0"))
 X = set(filter(None, os.environ.get("GEN_X", "").split(",")))   # novalu, nodma, nobarrier, nofrag, nowait, nowaitv
-SPREAD = int(os.environ.get("GEN_SPREAD", "2"))  # > 0: one LDS-DMA piece every SPREAD MFMAs instead of all after the barrier
+SPREAD = int(os.environ.get("GEN_SPREAD", "-1"))  # > 0: one LDS-DMA piece every SPREAD MFMAs; -1: pieces go into the cheapest gaps (least VALU/LDS work) of the chunk; 0: all after the barrier
 WAITB = int(os.environ.get("GEN_WAITB", "4"))    # one s_waitcnt per WAITB weight fragments
 BSPREAD = int(os.environ.get("GEN_BSPREAD", "2"))  # > 0: bias ds_reads spread, BSPREAD per gap
 SKEW = int(os.environ.get("GEN_SKEW", "0"))      # > 0: after every ring hand-off wave w idles w * SKEW wait states
@@ -334,6 +334,13 @@ class Body:
             assert not getattr(self, "dma_pending", []), "previous chunk's pieces not issued yet"
             self.dma_pending = [p for p in range(loads)]
             self.dma_count = 0
+            if SPREAD < 0:
+                # slack-aware: the `loads` cheapest of the next gaps (by the issue cost of what is already placed
+                # there), leaving the last two gaps before the next hand-off alone
+                g0 = self.cur_gap
+                cand = [g for g in range(g0, min(g0 + c.cf - 2, self.nfrags))]
+                cand.sort(key=lambda g: (self.gapcost.get(g, 0), g))
+                self.dma_gaps = set(cand[:loads])
             return
         self.emit("s_nop 0")
         for p in range(loads):
@@ -354,6 +361,12 @@ class Body:
             return
         pend = getattr(self, "dma_pending", [])
         self.dma_count = getattr(self, "dma_count", 0) + 1
+        if SPREAD < 0:
+            while pend and (flush or self.cur_gap in getattr(self, "dma_gaps", ())):
+                self.piece(pend.pop(0))
+                if not flush:
+                    break
+            return
         while pend and (flush or self.dma_count % SPREAD == 0):
             self.piece(pend.pop(0))
             if not flush:
@@ -426,6 +439,13 @@ class Body:
             t["window"] = (lo, hi)
         for t in self.tiles:
             bias_at.setdefault(t["bias_gap"], []).extend(t["bias"])
+        # issue cost (cycles) of what each gap already holds: VALU, bias reads; used to place the DMA pieces
+        self.gapcost = {}
+        for g, ops in valu_at.items():
+            self.gapcost[g] = sum(8 if op.trans else 4 for op in ops)
+        for g, bl in bias_at.items():
+            self.gapcost[g] = self.gapcost.get(g, 0) + 16 * len(bl)
+        self.cur_gap = -1
         # ---- prologue: last_block bias into its accumulator, first biases, queue priming
         for q in range(4):
             self.emit("ds_read_b128 %s, %%[bias] offset:%d" % (aq(A_ACCL + 4 * q), (c.B_LAST + 8 * q) * 4))
@@ -447,6 +467,7 @@ class Body:
         for n in range(min(PF, nf)):
             self.frag_read(n)
         for g, m in enumerate(self.mf):
+            self.cur_gap = g
             for op in forced.get(g, []):
                 self.emit(op.text)
             # operands ready?

@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out; rm -f gpurun_out/parity_errors.log
-timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread -p no:cacheprovider > gpurun_out/gpu_tests_a.log 2>&1; tail -3 gpurun_out/gpu_tests_a.log
-timeout -k 10 300 python -u scripts/quick_bf16.py 2>&1 | grep -v amdgpu.ids | tail -3
+for l in slack; do
+echo "== $l"; GRLHIP_LIB=$PWD/generativerl_preview_amd/lib_$l.so timeout -k 10 300 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread -p no:cacheprovider -k "bf16_ode_sampling" 2>&1 | tail -1
+done
+timeout -k 10 400 python -u scripts/xtime.py generativerl_preview_amd/lib_base.so generativerl_preview_amd/lib_slack.so generativerl_preview_amd/lib_sp1.so generativerl_preview_amd/lib_sp3.so generativerl_preview_amd/lib_base.so 2>&1 | grep -v amdgpu.ids
