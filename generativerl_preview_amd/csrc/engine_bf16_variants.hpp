@@ -16,10 +16,10 @@ template <> struct AsmBodyFor<CfgQgpo> { using type = b16::AsmBody_cond_6_17; };
 template <> struct AsmBodyFor<CfgSwiss> { using type = b16::AsmBody_uncond_2; };
 #endif
 constexpr int B16_NSLOT = B16_NSLOT_V, B16_CF = B16_CF_V, B16_P = B16_P_V;  // ring slots, fragments per chunk, register prefetch depth
-// The assembly-body kernels need no LDS parking and use the space for a deeper ring: the weight stream is latency
-// bound (Little's law: chunks in flight x 16 KiB per ~1 us of L2 latency under load), not bandwidth bound.
+// Ring of the assembly-body kernels.  Measured (profiles/r02_asm_body_experiments.md): 4, 6 and 8 slots run at the
+// same speed, so the smallest is kept and the LDS goes to the input park slots.
 #ifndef B16_NSLOT_ASM_V
-#define B16_NSLOT_ASM_V 8
+#define B16_NSLOT_ASM_V 4
 #endif
 #ifndef B16_CF_ASM_V
 #define B16_CF_ASM_V B16_CF_V

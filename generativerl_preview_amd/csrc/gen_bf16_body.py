@@ -39,18 +39,19 @@ SPREAD = int(os.environ.get("GEN_SPREAD", "-1"))  # > 0: one LDS-DMA piece every
 WAITB = int(os.environ.get("GEN_WAITB", "4"))    # one s_waitcnt per WAITB weight fragments
 BSPREAD = int(os.environ.get("GEN_BSPREAD", "2"))  # > 0: bias ds_reads spread, BSPREAD per gap
 SKEW = int(os.environ.get("GEN_SKEW", "0"))      # > 0: after every ring hand-off wave w idles w * SKEW wait states
-NV = 224            # VGPRs the body owns: v[0:NV-1]
 ACC = (0, 32)       # two accumulator buffers of 32 registers
 HB = 64             # 32 fragments x 4
 QBASE = 192
-QSLOTS = int(os.environ.get("GEN_PF", "8"))   # weight-fragment queue depth: 6 VGPR slots + up to 4 AGPR slots (a[240:255])
-TMP = 216           # 8 temporaries
+QSLOTS = int(os.environ.get("GEN_PF", "8"))   # weight-fragment queue depth: 4 AGPR slots (a[240:255]) + the rest in VGPRs
+QV = max(QSLOTS - 4, 0)                        # VGPR slots
+TMP = QBASE + 4 * QV                           # 8 epilogue temporaries
+NV = TMP + 8                                   # VGPRs the body owns: v[0:NV-1]; the rest is the compiler's
 A_STE, A_ACCL, A_R1, A_R2 = 0, 32, 48, 176
 
 
 class Cfg:
     def __init__(self, name, XD, CD, CH, TD, TCH, H0, H1, H2, nslot=None, cf=None):
-        nslot = nslot or int(os.environ.get("GEN_NSLOT", "8"))
+        nslot = nslot or int(os.environ.get("GEN_NSLOT", "4"))
         cf = cf or int(os.environ.get("GEN_CF", "16"))
         self.name = name
         self.XD, self.CD, self.CH, self.TD, self.TCH, self.H0, self.H1, self.H2 = XD, CD, CH, TD, TCH, H0, H1, H2
@@ -82,8 +83,8 @@ def aq(b):
 def qslot(n):
     """Register quad of weight-queue slot n % QSLOTS."""
     k = n % QSLOTS
-    assert QSLOTS <= 10
-    return vq(QBASE + 4 * k) if k < 6 else aq(240 + 4 * (k - 6))
+    assert 4 <= QSLOTS <= 10
+    return vq(QBASE + 4 * k) if k < QV else aq(240 + 4 * (k - QV))
 
 
 class Op:
@@ -241,8 +242,11 @@ class Body:
         ste = [aq(A_STE + 4 * i) for i in range(c.KS_T)]
         r1 = [A_R1 + 4 * i for i in range(32)]
         r2 = [A_R2 + 4 * i for i in range(16)]
-        tc = ["%%[tc%d]" % i for i in range(c.KS_T0)]
-        xb = ["%[xb]"]
+        # [t_emb | c_emb] and x fragments: written by the caller to this lane's park slots in LDS, read at the top of
+        # the body into the d1 registers (free until down0 writes d1, long after the first block)
+        assert c.KS_T0 + 1 <= c.K1
+        tc = [aq(A_R2 + 4 * i) for i in range(c.KS_T0)]
+        xb = [aq(A_R2 + 4 * c.KS_T0)]
         # ---- sort_t.0 -> z (hb[0:KS_T)), sort_t.2 -> ste
         for n in range(c.NT_T):
             t = self.new_tile("s")
@@ -381,8 +385,8 @@ class Body:
         if "nofrag" in X:
             self.frag_seq[n] = self.lds_seq
             return
-        base = "%[rd]" if pos < 64 else "%[rd2]"      # 16-bit immediate: second base register for the upper 64 KiB
-        self.emit("ds_read_b128 %s, %s offset:%d" % (qslot(n), base, (pos % 64) * 1024))
+        assert pos < 64, "the ring must fit the 16-bit immediate offset of ds_read"
+        self.emit("ds_read_b128 %s, %%[rd] offset:%d" % (qslot(n), pos * 1024))
         self.frag_seq[n] = self.lds_issue()
 
     def generate(self):
@@ -446,7 +450,10 @@ class Body:
         for g, bl in bias_at.items():
             self.gapcost[g] = self.gapcost.get(g, 0) + 16 * len(bl)
         self.cur_gap = -1
-        # ---- prologue: last_block bias into its accumulator, first biases, queue priming
+        # ---- prologue: parked inputs, last_block bias into its accumulator, first biases, queue priming
+        for i in range(c.KS_T0 + 1):
+            self.emit("ds_read_b128 %s, %%[park] offset:%d" % (aq(A_R2 + 4 * i), i * 1024))
+            self.lds_issue()
         for q in range(4):
             self.emit("ds_read_b128 %s, %%[bias] offset:%d" % (aq(A_ACCL + 4 * q), (c.B_LAST + 8 * q) * 4))
             accl_seq = self.lds_issue()
@@ -531,17 +538,17 @@ def function_text(cfg):
         cfg.name, b.nfrags, len(lines), ", ".join("%s %d" % kv for kv in sorted(cnt.items(), key=lambda kv: -kv[1])[:12])))
     o.append("struct AsmBody_%s {" % cfg.name)
     o.append("  static constexpr bool ON = true;")
-    o.append("  static constexpr int FRAGS = %d, NSLOT = %d, CF = %d, KS_T0 = %d, INSTRUCTIONS = %d;" % (
-        b.nfrags, cfg.nslot, cfg.cf, ntc, len(lines)))
-    o.append("  static __device__ __forceinline__ void run(const bf16x8* tc, const bf16x8& xb, uint32_t voff, uint32_t rd, "
-             "uint32_t rd2, uint32_t bias, i32x4 rsrc, uint32_t ldsw, uint32_t wid, float* o) {")
+    o.append("  static constexpr int FRAGS = %d, NSLOT = %d, CF = %d, KS_T0 = %d, PARK_FRAGS = %d, INSTRUCTIONS = %d;" % (
+        b.nfrags, cfg.nslot, cfg.cf, ntc, ntc + 1, len(lines)))
+    o.append("  // park: LDS address of this lane's PARK_FRAGS input fragments ([t_emb | c_emb] then x), 1 KiB apart")
+    o.append("  static __device__ __forceinline__ void run(uint32_t park, uint32_t voff, uint32_t rd, uint32_t bias, "
+             "i32x4 rsrc, uint32_t ldsw, uint32_t wid, float* o) {")
     o.append("    uint32_t soff;")
     o.append("    asm volatile(")
     for l in lines:
         o.append('      "%s\\n\\t"' % l)
     outs = ", ".join('[o%d] "=v"(o[%d])' % (i, i) for i in range(8)) + ', [soff] "=&s"(soff)'
-    ins = ", ".join('[tc%d] "v"(tc[%d])' % (i, i) for i in range(ntc))
-    ins += ', [xb] "v"(xb), [voff] "v"(voff), [rd] "v"(rd), [rd2] "v"(rd2), [bias] "v"(bias), [rsrc] "s"(rsrc), [ldsw] "s"(ldsw), [wid] "s"(wid)'
+    ins = '[park] "v"(park), [voff] "v"(voff), [rd] "v"(rd), [bias] "v"(bias), [rsrc] "s"(rsrc), [ldsw] "s"(ldsw), [wid] "s"(wid)'
     clob = ['"memory"', '"scc"']
     clob += ['"v%d"' % i for i in range(NV)]
     clob += ['"a%d"' % i for i in range(256)]
