@@ -1,8 +1,12 @@
 // The network shapes the bf16 engine is instantiated for, and its ring geometry.
 #pragma once
 namespace grlhip {
-using CfgQgpo = b16::Cfg<6, 17, 32, 32, 128, 512, 256, 128>;  // QGPO / GMPO HalfCheetah: act 6, obs 17
-using CfgSwiss = b16::Cfg<2, 0, 0, 32, 32, 512, 256, 128>;    // swiss-roll tutorial: D = 2, unconditional
+// Shape classes (padded I/O widths; actual widths are run-time arguments of the kernel):
+//   CfgQgpo   conditional [512,256,128] nets of the QGPO / GMPO benchmark configs: action <= 16, observation <= 32
+//             when energy-guided, any width unguided (HalfCheetah / Walker2d 6/17, Hopper 3/11, Ant 8/27, ...)
+//   CfgSwiss  unconditional [512,256,128] nets, D <= 16 (swiss-roll tutorial: D = 2)
+using CfgQgpo = b16::Cfg<16, 32, 32, 32, 128, 512, 256, 128>;
+using CfgSwiss = b16::Cfg<16, 0, 0, 32, 32, 512, 256, 128>;
 using GuideQgpo = b16::GuideCfg<32, 256, 256>;                // QGPO energy net: ConcatenateMLP [55, 256, 256] -> 1
 #ifndef B16_NSLOT_V
 #define B16_NSLOT_V 4
@@ -12,8 +16,8 @@ using GuideQgpo = b16::GuideCfg<32, 256, 256>;                // QGPO energy net
 #if defined(B16_ASM_BODY)
 // the generated assembly body of each sampler shape (engine_bf16_body_gen.inc)
 template <class C> struct AsmBodyFor;
-template <> struct AsmBodyFor<CfgQgpo> { using type = b16::AsmBody_cond_6_17; };
-template <> struct AsmBodyFor<CfgSwiss> { using type = b16::AsmBody_uncond_2; };
+template <> struct AsmBodyFor<CfgQgpo> { using type = b16::AsmBody_cond; };
+template <> struct AsmBodyFor<CfgSwiss> { using type = b16::AsmBody_uncond; };
 #endif
 constexpr int B16_NSLOT = B16_NSLOT_V, B16_CF = B16_CF_V, B16_P = B16_P_V;  // ring slots, fragments per chunk, register prefetch depth
 // Ring of the assembly-body kernels.  Measured (profiles/r02_asm_body_experiments.md): 4, 6 and 8 slots run at the

@@ -561,8 +561,10 @@ def function_text(cfg):
 
 
 CONFIGS = [
-    Cfg("cond_6_17", 6, 17, 32, 32, 128, 512, 256, 128),
-    Cfg("uncond_2", 2, 0, 0, 32, 32, 512, 256, 128),
+    # shape classes of engine_bf16_variants.hpp: the body depends on the hidden shape only (state <= 16 features in
+    # one k-step; the condition embedding is computed outside the body)
+    Cfg("cond", 16, 32, 32, 32, 128, 512, 256, 128),
+    Cfg("uncond", 16, 0, 0, 32, 32, 512, 256, 128),
 ]
 
 if __name__ == "__main__":

@@ -272,6 +272,14 @@ int grlhip_sample_ode(const grlhip_plan* plan, const void* packed, int dtype, co
                        out_final, out_traj, workspace, workspace_bytes, stream);
 }
 
+int grlhip_bf16_fused_kernel(const grlhip_plan* plan, const grlhip_plan* guidance, char* name_buf, size_t name_buf_len) {
+  if (!plan || !plan->p) return fail(GRLHIP_ERR_INVALID, "null plan");
+  const Plan* g = guidance ? guidance->p : nullptr;
+  const char* nm = bf16_fused_ok(plan->p) ? bf16_kernel_name(plan->p, g) : "";
+  if (name_buf && name_buf_len) snprintf(name_buf, name_buf_len, "%s", nm);
+  return nm[0] ? 1 : 0;
+}
+
 // ---- allocation-free variant of grlhip_sample_ode (include/grlhip.h): the fused bf16 integrator with its
 // workspace (per-step Fourier tables, spliced guided weight stream) in a file-scope device array instead of a
 // caller workspace.  In host code `g_static_scratch` is only a stand-in for the symbol: the device address is

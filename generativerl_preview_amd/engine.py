@@ -73,6 +73,15 @@ class NetPlan:
         except Exception:
             pass
 
+    def fused_kernel(self, guidance=None):
+        """Name of the persistent fused bf16 integrator that GRLHIP_BF16 sampling of this plan (energy-guided by the
+        plan `guidance`) runs, or "" when it runs layer by layer on the batch engine (grlhip_bf16_fused_kernel)."""
+        buf = ctypes.create_string_buffer(160)
+        rc = L.lib().grlhip_bf16_fused_kernel(self.handle, guidance.handle if guidance is not None else None, buf, 160)
+        if rc < 0:
+            L.check(rc)
+        return buf.value.decode()
+
     def packed_bytes(self, dtype=L.F32):
         return L.lib().grlhip_packed_bytes(self.handle, dtype)
 

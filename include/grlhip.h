@@ -90,6 +90,13 @@ int grlhip_plan_param_info(const grlhip_plan* plan, int index, char* name_buf, s
  * linear whose only consumer is the residual input of the next linear is fused into that GEMM). */
 int grlhip_plan_program_info(const grlhip_plan* plan, int program, int32_t* n_ops, int32_t* n_launches);
 
+/* Introspection (no counterpart in the reference): 1 when GRLHIP_BF16 sampling of `plan` (energy-guided by
+ * `guidance`, may be NULL) runs the persistent fused integrator k_sample_bf16 -- any conditional or unconditional
+ * [512,256,128] TemporalSpatialResidualNet with at most 16 state features (guided: at most 32 condition features and
+ * a [256,256] energy net) -- and 0 when it runs layer by layer on the batch engine.  name_buf (optional) receives
+ * the kernel class. */
+int grlhip_bf16_fused_kernel(const grlhip_plan* plan, const grlhip_plan* guidance, char* name_buf, size_t name_buf_len);
+
 /* Bytes of the packed weight image for `dtype` (the image layout is private to the library and differs
  * per dtype and shape: always produce it with grlhip_pack_weights for the same plan and dtype). */
 size_t grlhip_packed_bytes(const grlhip_plan* plan, int dtype);

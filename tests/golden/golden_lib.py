@@ -58,6 +58,11 @@ def model_zoo():
     zoo = {}
     # C2/C4: QGPO HalfCheetah (benchmark/qgpo/vpsde/halfcheetah_medium_expert.py:99-130)
     zoo["qgpo_noise"] = ("energy", diffusion_cfg(6, VP, "noise_function", [512, 256, 128], 17, energy=True))
+    # other environments of the same benchmark family hit the same fused kernel class (padded I/O widths):
+    # Hopper (benchmark/qgpo/vpsde/hopper_medium.py:4-5,99-130: action 3, observation 11), energy-guided, and a wide
+    # observation (antmaze-like: action 8, observation 44 = three condition k-steps), unguided
+    zoo["hopper_noise"] = ("energy", diffusion_cfg(3, VP, "noise_function", [512, 256, 128], 11, energy=True))
+    zoo["wideobs_noise"] = ("diffusion", diffusion_cfg(8, VP, "noise_function", [512, 256, 128], 44))
     # C1: swiss roll tutorial (unconditional, D=2)
     zoo["swiss_noise"] = ("diffusion", diffusion_cfg(2, VP, "noise_function", [512, 256, 128]))
     # C3: GMPO ICFM
@@ -116,7 +121,10 @@ def make_weights(model_name, key_shapes):
 # :206-217 as written, so training drives the reverse ODE to diverge: 2e12 after 100 steps), small_vp_data (no loss
 # of the reference accepts a data-prediction head), small_gvp_score (tan(pi/2) at the first step).  Those keep the
 # seeded init and their trajectory checks stay RELATIVE to max|ref|.
-TRAINED = ("qgpo_noise", "swiss_noise", "small_vp_noise", "small_vp_velocity", "small_energy", "small_uncond_noise")
+TRAINED = ("qgpo_noise", "swiss_noise", "small_vp_noise", "small_vp_velocity", "small_energy", "small_uncond_noise",
+           "hopper_noise", "wideobs_noise")
+# trained weights rounded to fp16 before they are stored and used (halves the fixture; exact in fp32 on both sides)
+STORED_F16 = ("hopper_noise", "wideobs_noise")
 
 
 def toy_data(name, rows, x_dim, cond_dim, seed):

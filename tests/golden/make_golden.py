@@ -277,6 +277,8 @@ one_model("qgpo_noise", 40, full_grads=False)
 one_model("swiss_noise", 40, full_grads=False)
 one_model("icfm_cond", 40, full_grads=False)
 one_model("gvp_wide", 24, full_grads=False)
+one_model("hopper_noise", 40, full_grads=False)
+one_model("wideobs_noise", 40, full_grads=False)
 for nm in gl.model_zoo():
     if nm.startswith("small_"):
         one_model(nm, 37, full_grads=True)

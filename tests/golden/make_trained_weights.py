@@ -37,7 +37,7 @@ for name in gl.TRAINED:
     m.load_state_dict({k: torch.from_numpy(v) for k, v in gl.make_weights(name, key_shapes).items()})
     D = cfg.x_size
     S = cfg.model.args.backbone.args.get("condition_dim", None)
-    big = name in ("qgpo_noise", "swiss_noise")
+    big = name in ("qgpo_noise", "swiss_noise", "hopper_noise", "wideobs_noise")
     steps, batch, lr = (400, 1024, 1e-3) if big else (600, 512, 3e-3)
     params = [p for k, p in m.named_parameters() if k.startswith("model.") and p.requires_grad]
     opt = torch.optim.Adam(params, lr=lr)
@@ -56,6 +56,11 @@ for name in gl.TRAINED:
         opt.step()
         if it % 100 == 0 or it == steps - 1:
             print(name, it, float(loss), flush=True)
+    if name in gl.STORED_F16:
+        with torch.no_grad():
+            for v in m.state_dict().values():
+                if v.dtype == torch.float32:
+                    v.copy_(v.half().float())
     # how large do 100-step samples get?
     with torch.no_grad():
         xt, ct = gl.toy_data(name, 64, D, S, 10 ** 6)
@@ -67,5 +72,6 @@ for name in gl.TRAINED:
         out = m.sample(**kw)
         print(name, "max |sample| after 100 Euler steps: %.3f" % float(out.abs().max()), flush=True)
     np.savez_compressed(os.path.join(HERE, "weights_%s.npz" % name),
-                        **{k: v.detach().numpy().astype(np.float32) for k, v in m.state_dict().items()})
+                        **{k: v.detach().numpy().astype(np.float16 if name in gl.STORED_F16 else np.float32)
+                           for k, v in m.state_dict().items()})
 print("done")

@@ -13,7 +13,7 @@ with open(os.path.join(GOLDEN, "manifest.json")) as _f:
     MANIFEST = json.load(_f)
 
 SMALL = [n for n in MANIFEST["models"] if n.startswith("small_")]
-CANON = ["qgpo_noise", "swiss_noise", "icfm_cond", "gvp_wide"]
+CANON = ["qgpo_noise", "swiss_noise", "icfm_cond", "gvp_wide", "hopper_noise", "wideobs_noise"]
 
 
 def model_info(name):

@@ -84,7 +84,7 @@ def test_head_conversions_vs_golden(name):
     assert n >= 3
 
 
-@pytest.mark.parametrize("name", ["qgpo_noise", "small_energy"])
+@pytest.mark.parametrize("name", ["qgpo_noise", "small_energy", "hopper_noise"])
 def test_energy_guidance_vs_golden(name):
     kind, cfg, m = um.build(name, DEV)
     g = gu.load("model_%s.npz" % name)
@@ -211,9 +211,13 @@ def _bf16_model(name):
 
 
 @pytest.mark.parametrize("name,rows,steps", [("qgpo_noise", 1000, 100), ("icfm_cond", 300, 100),
-                                             ("swiss_noise", 500, 100), ("qgpo_noise", 128 * 300 + 5, 10)])
+                                             ("swiss_noise", 500, 100), ("qgpo_noise", 128 * 300 + 5, 10),
+                                             ("hopper_noise", 1000, 100), ("wideobs_noise", 700, 100)])
 def test_bf16_ode_sampling_vs_oracle(name, rows, steps):
+    """Every [512,256,128] net runs the persistent fused integrator, whatever its action / observation widths (shape
+    CLASSES with run-time widths: Hopper 3/11, a 44-wide observation = three condition k-steps)."""
     kind, cfg, m, sd = _bf16_model(name)
+    assert "k_sample_bf16" in m.model.plan.fused_kernel(), "bf16 sampling of %s would not run the fused integrator" % name
     S = gu.cond_dim(cfg)
     D = cfg["x_size"]
     gen = torch.Generator().manual_seed(11)
@@ -251,10 +255,10 @@ def test_bf16_trajectory_and_sde_vs_golden():
         close(out[-1], s["sde_T%d" % Tn][-1], tol=BF16_TOL, what="bf16 swiss sde final T%d" % Tn)
 
 
-def _bf16_energy_model():
-    kind, cfg, m = um.build("qgpo_noise", DEV)
+def _bf16_energy_model(name="qgpo_noise"):
+    kind, cfg, m = um.build(name, DEV)
     m.model.compute_dtype = L.BF16
-    return cfg, m, gu.weights("qgpo_noise")
+    return cfg, m, gu.weights(name)
 
 
 def test_bf16_guided_sampling_vs_golden():
@@ -283,18 +287,22 @@ def test_bf16_guided_sampling_vs_golden():
             close(out[-1], s["sde_T%d_g%d" % (Tn, gs)][-1], tol=BF16_TOL, what="bf16 guided sde final T%d g%d" % (Tn, gs))
 
 
-@pytest.mark.parametrize("rows,steps,scale", [(1000, 100, 10.0), (128 * 260 + 37, 10, 30.0)])
-def test_bf16_guided_ode_vs_oracle(rows, steps, scale):
-    cfg, m, sd = _bf16_energy_model()
+@pytest.mark.parametrize("name,rows,steps,scale", [("qgpo_noise", 1000, 100, 10.0), ("qgpo_noise", 128 * 260 + 37, 10, 30.0),
+                                                   ("hopper_noise", 900, 100, 10.0)])
+def test_bf16_guided_ode_vs_oracle(name, rows, steps, scale):
+    cfg, m, sd = _bf16_energy_model(name)
+    D, S = cfg["x_size"], gu.cond_dim(cfg)
     gen = torch.Generator().manual_seed(23)
-    x0 = torch.randn(rows, 6, generator=gen)
-    cond = torch.randn(rows, 17, generator=gen)
+    x0 = torch.randn(rows, D, generator=gen)
+    cond = torch.randn(rows, S, generator=gen)
     t_span = torch.linspace(0.0, 1.0, steps + 1)
     got = m.sample(t_span=t_span, x_0=x0.to(DEV), condition=cond.to(DEV), guidance_scale=scale).cpu()
+    fk = m.model.plan.fused_kernel(m.energy_guidance.model.plan)
+    assert "k_sample_bf16" in fk and "energy-guided" in fk, fk
     worst = 0.0
     for sl in (slice(0, min(rows, 1024)), slice(max(0, rows - 64), rows)):
         want = O.sample_forward_process(sd, cfg, "energy", t_span, x_0=x0[sl], condition=cond[sl], guidance_scale=scale)[-1]
-        close(got[sl], want, tol=BF16_TOL, what="bf16 guided %d rows %d steps scale %g" % (rows, steps, scale))
+        close(got[sl], want, tol=BF16_TOL, what="bf16 guided %s %d rows %d steps scale %g" % (name, rows, steps, scale))
         worst = max(worst, float((got[sl] - want).abs().max()))
     # the guidance term must matter at this scale (otherwise the test proves nothing): leaving it out moves the
     # actions by several times the error the guided kernel makes
@@ -311,6 +319,7 @@ def test_bf16_generic_shapes_run_on_the_batch_engine(name, rows, steps):
     """Shapes without a fused bf16 kernel (C5's [1024] net, the small nets): GRLHIP_BF16 runs the batch engine
     with bf16 MFMAs (fp32 activations in HBM, bf16 operands, fp32 accumulate) -- same 2e-2 tolerance."""
     kind, cfg, m, sd = _bf16_model(name)
+    assert m.model.plan.fused_kernel() == ""
     S = gu.cond_dim(cfg)
     D = cfg["x_size"]
     gen = torch.Generator().manual_seed(17)
