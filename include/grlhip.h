@@ -212,6 +212,10 @@ int64_t grlhip_grad_offset(const grlhip_plan* plan, int index);
  *   pred = alpha[r]*net(t[r], x_t[r], c[r]) + beta[r]*x_t[r];  loss_r = sum_d 0.5*(pred - target)^2
  * loss_rows[R] receives loss_r; grad_flat (+=) receives sum_r row_weight[r] * d loss_r / d theta
  * (row_weight NULL = 1).  grad_flat is NOT zeroed by the call.
+ * Gradients are bit-reproducible from call to call: the contraction over the rows is split into a fixed number of
+ * slices (independent of the device), whose partial sums are added in order (no float atomics).
+ * Arithmetic of every GRLHIP_F32 contraction: fp32 operands split exactly into three bf16 pieces, six bf16 MFMAs with
+ * fp32 accumulation per product -- fp32 rounding level, on the bf16 matrix cores.
  * QNET plans (the two regressions of QGPOCritic.q_loss, grl/algorithms/qgpo.py:132-139): x_t = action, cond = state,
  * t and beta ignored (may be NULL), pred = alpha[r]*q(action, state), target[R,1]. */
 int grlhip_loss_fwd_bwd(const grlhip_plan* plan, const void* packed, int dtype, const float* t,

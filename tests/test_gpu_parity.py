@@ -447,6 +447,26 @@ def test_weighted_rows_backward_and_trainable_fourier():
             close(p.grad, grads[k], tol=3e-4, what=k, rel=True)
 
 
+def test_gradients_are_bit_reproducible():
+    """Two backward passes over the same batch (20 000 rows: many row slices per dW launch, trainable Fourier W) give
+    bit-identical gradients: the slices' partial sums are added in a fixed order, no float atomics."""
+    name = "icfm_cond"
+    kind, cfg, m = um.build(name, DEV)
+    m.model.model["t_encoder"].W.requires_grad_(True)
+    gen = torch.Generator().manual_seed(5)
+    B = 20000
+    x0, x1 = torch.randn(B, 6, generator=gen).to(DEV), torch.rand(B, 6, generator=gen).to(DEV)
+    cond, t, eps = torch.randn(B, 17, generator=gen).to(DEV), torch.rand(B, generator=gen).to(DEV), torch.randn(B, 6, generator=gen).to(DEV)
+    runs = []
+    for _ in range(2):
+        m.zero_grad(set_to_none=True)
+        m.flow_matching_loss(x0, x1, cond, t=t, noise=eps).backward()
+        runs.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    assert len(runs[0]) > 10
+    for k in runs[0]:
+        assert torch.equal(runs[0][k], runs[1][k]), "gradient of %s differs between two identical passes" % k
+
+
 def test_training_batch_spanning_two_chunks_vs_oracle():
     """The batch engine walks the rows in chunks of 65 536: per-row losses and every gradient of a batch
     that crosses the boundary (and is not a multiple of the 128-row tile) against torch autograd on the oracle."""
