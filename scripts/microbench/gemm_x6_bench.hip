@@ -1,0 +1,42 @@
+// Microbenchmark of k_bt_gemm_x6 on one 512x512 layer at 65 536 rows (the shape that dominates the C3 training step),
+// three epilogue modes.  Results and the phase-removal experiments made with it: profiles/r02_gemm_x6_microbench.md.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I generativerl_preview_amd/csrc -o gemm_x6_bench scripts/microbench/gemm_x6_bench.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#include <algorithm>
+#include <string>
+#include <cstdlib>
+#include "plan.hpp"
+namespace grlhip { inline int device_cus() { return 256; } }
+#include "engine_batch.hip.inc"
+using namespace grlhip;
+int main(int argc, char** argv) {
+  const int M = 512, K = 512; const int64_t ld = argc > 1 ? atoll(argv[1]) : 65536;
+  float *A, *B, *C, *pre, *add, *bias;
+  hipMalloc(&A, (size_t)K * M * 4); hipMalloc(&B, (size_t)K * ld * 4); hipMalloc(&C, (size_t)M * ld * 4);
+  hipMalloc(&pre, (size_t)M * ld * 4); hipMalloc(&add, (size_t)M * ld * 4); hipMalloc(&bias, M * 4);
+  hipMemset(A, 0, (size_t)K * M * 4); hipMemset(B, 0, (size_t)K * ld * 4); hipMemset(add, 0, (size_t)M * ld * 4); hipMemset(bias, 0, M * 4);
+  std::vector<float> h((size_t)K * M); for (auto& v : h) v = (rand() % 2001 - 1000) * 1e-4f;
+  hipMemcpy(A, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+  std::vector<float> hb((size_t)K * 4096); for (auto& v : hb) v = (rand() % 2001 - 1000) * 1e-3f;
+  for (int64_t o = 0; o < K * ld; o += hb.size()) hipMemcpy(B + o, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
+  for (int mode = 0; mode < 3; ++mode) {
+    bt::GemmArgs g{};
+    g.A = A; g.bias = bias; g.B = B; g.C = C; g.M = M; g.K = K; g.lda = M; g.ld = ld;
+    g.pre = mode >= 1 ? pre : nullptr; g.add = mode >= 2 ? add : nullptr; g.flags = mode >= 1 ? (F_SILU_OUT | F_SAVE_PRE) : 0;
+    const dim3 grid((unsigned)((ld / bt::BN) * ((M + bt::BM - 1) / bt::BM)));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((bt::k_bt_gemm_x6<false, 2>), grid, dim3(256), 0, 0, g);
+    hipEventRecord(e0);
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((bt::k_bt_gemm_x6<false, 2>), grid, dim3(256), 0, 0, g);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double us = ms * 100.0;
+    printf("ld %lld mode %d (%s): %.1f us  %.1f TFLOP/s fp32-equivalent  %.2f TB/s min traffic\n", (long long)ld, mode,
+           mode == 0 ? "plain" : mode == 1 ? "silu+pre" : "silu+pre+add", us, 2.0 * M * K * ld / us * 1e-6,
+           ((double)(K + M * (1 + (mode >= 1) + (mode >= 2))) * ld * 4) / us * 1e-6);
+  }
+  return 0;
+}
