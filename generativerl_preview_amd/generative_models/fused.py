@@ -106,9 +106,10 @@ class FusedDrift:
     def integrate_with_grad(self, x0, table):
         """Differentiable Euler chain (``with_grad=True``): the fp32 trajectory (n_steps + 1, R, D) with a grad_fn whose
         backward walks the chain in the library (grlhip_sample_ode_backward) -- gradients reach the model's parameters
-        and x0, not the condition.  Every step of ``table`` must emit slot k + 1 with lerp 1."""
-        if self.guidance is not None:
-            raise NotImplementedError("differentiable sampling of energy-guided models is not implemented")
+        and x0, not the condition.  Every step of ``table`` must emit slot k + 1 with lerp 1.
+        Energy-guided chains: the reference detaches the guidance term (``calculate_energy_guidance`` returns
+        ``guidance.detach()``, energy_conditional_diffusion_model.py:87-92), so it enters the forward chain only; the
+        backward is the unguided chain rule along the guided trajectory, with no gradient to the energy net."""
         named = self.model._named()
         params = [named[n] for n, _ in self.model.plan.params]
         return _DifferentiableOde.apply(self, table, x0, *params)
@@ -124,7 +125,11 @@ class _DifferentiableOde(torch.autograd.Function):
     def forward(ctx, drift, table, x0, *params):
         m = drift.model
         n = table.shape[0]
-        _, traj = m.plan.sample(m.packed(L.F32), x0, drift.condition, table, trajectory_slots=n + 1, dtype=L.F32)
+        g_plan = g_packed = None
+        if drift.guidance is not None:
+            g_plan, g_packed = drift.guidance.plan, drift.guidance.packed(L.F32)
+        _, traj = m.plan.sample(m.packed(L.F32), x0, drift.condition, table, guidance=g_plan, guidance_packed=g_packed,
+                                trajectory_slots=n + 1, dtype=L.F32)
         ctx.drift, ctx.table = drift, table
         ctx.save_for_backward(traj)
         return traj

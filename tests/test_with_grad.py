@@ -18,26 +18,27 @@ def _objective(a, w):
     return (torch.tanh(a) * w).sum() / a.shape[0] + 0.05 * a.pow(2).mean()
 
 
-def _run(name, rows, steps, traj_loss=False):
+def _run(name, rows, steps, traj_loss=False, guidance_scale=None):
     kind, cfg, m = um.build(name, DEV)
+    gkw = {} if guidance_scale is None else dict(guidance_scale=guidance_scale)
     gen = torch.Generator().manual_seed(9)
     x0, cond = torch.randn(rows, 6, generator=gen), torch.randn(rows, 17, generator=gen)
     w = torch.randn(rows, 6, generator=gen)
     t_span = torch.linspace(0, 1, steps + 1)
     x0d = x0.to(DEV).requires_grad_(True)
     if traj_loss:
-        traj = m.sample_forward_process(t_span=t_span.to(DEV), x_0=x0d, condition=cond.to(DEV), with_grad=True)
+        traj = m.sample_forward_process(t_span=t_span.to(DEV), x_0=x0d, condition=cond.to(DEV), with_grad=True, **gkw)
         assert traj.shape == (steps + 1, rows, 6) and traj.requires_grad
         loss = _objective(traj[-1], w.to(DEV)) + 0.3 * _objective(traj[steps // 2], w.to(DEV))
     else:
-        a = m.sample(t_span=t_span.to(DEV), x_0=x0d, condition=cond.to(DEV), with_grad=True)
+        a = m.sample(t_span=t_span.to(DEV), x_0=x0d, condition=cond.to(DEV), with_grad=True, **gkw)
         assert a.shape == (rows, 6) and a.requires_grad
         loss = _objective(a, w.to(DEV))
     loss.backward()
     sd = {k: (v.clone().requires_grad_(True) if k.startswith("model.") and not k.endswith("t_encoder.W") else v)
           for k, v in gu.weights(name).items()}
     x0r = x0.clone().requires_grad_(True)
-    ref = O.sample_forward_process(sd, cfg, kind, t_span, x_0=x0r, condition=cond)
+    ref = O.sample_forward_process(sd, cfg, kind, t_span, x_0=x0r, condition=cond, **gkw)
     want = _objective(ref[-1], w) + (0.3 * _objective(ref[steps // 2], w) if traj_loss else 0.0)
     keys = [k for k, v in sd.items() if v.requires_grad]
     grads = torch.autograd.grad(want, [sd[k] for k in keys] + [x0r])
@@ -62,11 +63,18 @@ def test_gpu_trajectory_with_grad_and_two_chunks():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scale", [0.0, 3.0])
+def test_gpu_guided_sample_with_grad_vs_oracle_autograd(scale):
+    """Energy-guided chain, with_grad=True: the guidance term is detached in the reference
+    (energy_conditional_diffusion_model.py:87-92), so gradients follow the score net along the guided trajectory and the
+    energy net gets none."""
+    _run("small_energy", 150, 8, guidance_scale=scale)
+    _run("small_energy", 90, 6, traj_loss=True, guidance_scale=scale)
+
+
+@pytest.mark.gpu
 def test_gpu_with_grad_limits():
-    kind, cfg, m = um.build("small_energy", DEV)
     x0, c = torch.zeros(4, 6, device=DEV), torch.zeros(4, 17, device=DEV)
-    with pytest.raises(NotImplementedError):   # energy-guided chains: not implemented
-        m.sample(t_span=torch.linspace(0, 1, 5).to(DEV), x_0=x0, condition=c, with_grad=True)
     kind, cfg, m = um.build("small_vp_noise", DEV)
     with pytest.raises(NotImplementedError):   # DPM-Solver / SDE solvers: ODESolver only
         m.sample(x_0=x0, condition=c, with_grad=True, solver_config=dict(type="DPMSolver", args=dict(order=2, device=DEV, steps=5)))
