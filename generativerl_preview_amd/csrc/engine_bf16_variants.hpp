@@ -8,27 +8,14 @@ namespace grlhip {
 using CfgQgpo = b16::Cfg<16, 32, 32, 32, 128, 512, 256, 128>;
 using CfgSwiss = b16::Cfg<16, 0, 0, 32, 32, 512, 256, 128>;
 using GuideQgpo = b16::GuideCfg<32, 256, 256>;                // QGPO energy net: ConcatenateMLP [55, 256, 256] -> 1
-#ifndef B16_NSLOT_V
-#define B16_NSLOT_V 4
-#define B16_CF_V 16
-#define B16_P_V 8
-#endif
 #if defined(B16_ASM_BODY)
 // the generated assembly body of each sampler shape (engine_bf16_body_gen.inc)
-template <class C> struct AsmBodyFor;
-template <> struct AsmBodyFor<CfgQgpo> { using type = b16::AsmBody_cond; };
-template <> struct AsmBodyFor<CfgSwiss> { using type = b16::AsmBody_uncond; };
+template <class C, class G> struct AsmBodyFor;
+template <> struct AsmBodyFor<CfgQgpo, b16::NoGuide> { using type = b16::AsmBody_cond; };
+template <> struct AsmBodyFor<CfgSwiss, b16::NoGuide> { using type = b16::AsmBody_uncond; };
+template <> struct AsmBodyFor<CfgQgpo, GuideQgpo> { using type = b16::AsmBody_cond_guided; };
 #endif
-constexpr int B16_NSLOT = B16_NSLOT_V, B16_CF = B16_CF_V, B16_P = B16_P_V;  // ring slots, fragments per chunk, register prefetch depth
-// Ring of the assembly-body kernels.  Measured (profiles/r02_asm_body_experiments.md): 4, 6 and 8 slots run at the
-// same speed, so the smallest is kept and the LDS goes to the input park slots.
-#ifndef B16_NSLOT_ASM_V
-#define B16_NSLOT_ASM_V 4
-#endif
-#ifndef B16_CF_ASM_V
-#define B16_CF_ASM_V B16_CF_V
-#endif
-constexpr int B16_NSLOT_ASM = B16_NSLOT_ASM_V, B16_CF_ASM = B16_CF_ASM_V;
-// the packed stream is padded to a whole number of chunk groups of the deepest ring
-constexpr int B16_NSLOT_LAYOUT = B16_NSLOT_ASM > B16_NSLOT ? B16_NSLOT_ASM : B16_NSLOT;
+// Ring geometry (must match gen_bf16_body.py's GEN_NSLOT / GEN_CF).  Measured (profiles/r02_asm_body_experiments.md):
+// 4, 6 and 8 slots run at the same speed, so the smallest is kept and the LDS goes to the input park slots.
+constexpr int B16_NSLOT = 4, B16_CF = 16;   // ring slots, fragments per chunk
 }  // namespace grlhip

@@ -50,7 +50,7 @@ A_STE, A_ACCL, A_R1, A_R2 = 0, 32, 48, 176
 
 
 class Cfg:
-    def __init__(self, name, XD, CD, CH, TD, TCH, H0, H1, H2, nslot=None, cf=None):
+    def __init__(self, name, XD, CD, CH, TD, TCH, H0, H1, H2, nslot=None, cf=None, guide=None):
         nslot = nslot or int(os.environ.get("GEN_NSLOT", "4"))
         cf = cf or int(os.environ.get("GEN_CF", "16"))
         self.name = name
@@ -70,6 +70,21 @@ class Cfg:
         self.B_UP0 = self.B_MID + 3 * H2
         self.B_UP1 = self.B_UP0 + 3 * H1
         self.nslot, self.cf = nslot, cf
+        self.BIAS_FLOATS = self.B_UP1 + 3 * H0
+        # energy guidance (b16::GuideCfg): ConcatenateMLP [t_emb(GTD) | x | c] -> G1 -> G2 -> 1, forward + d/dx by hand
+        self.guide = guide
+        self.KS_C = (CD + 15) // 16
+        if guide:
+            self.GTD, self.G1, self.G2 = guide
+            self.GKT, self.GK1, self.GK2, self.GN1, self.GN2 = self.GTD // 16, self.G1 // 16, self.G2 // 16, self.G1 // 32, self.G2 // 32
+            self.GKS1 = self.GKT + self.KS_X + self.KS_C
+            self.GB_1, self.GB_2, self.GB_W3 = self.BIAS_FLOATS, self.BIAS_FLOATS + self.G1, self.BIAS_FLOATS + self.G1 + self.G2
+            assert self.G1 == self.G2 and self.GK1 * 4 * 2 <= 128
+        # park slots (1 KiB per fragment and lane set): [t_emb | c_emb] (KS_T0), x, then for guided bodies the energy
+        # net's t_emb fragments and the raw condition fragments
+        self.PARK_X = self.KS_T0
+        self.PARK_G = self.KS_T0 + 1
+        self.PARK_FRAGS = self.KS_T0 + 1 + ((self.GKT + self.KS_C) if guide else 0)
 
 
 def vq(b):
@@ -181,6 +196,100 @@ def silu_epilogue(pa, res_kind, res, out_kind, out, nt_tmp=4):
     return order_ops(ops)
 
 
+KD_INV_BITS = 0xbf317218   # -ln 2 = 1 / KD
+VK = TMP + 7               # guidance epilogues keep 1 / KD here (the main net's 'frag' epilogues use it as a temporary)
+
+
+def _pipeline(stages, n_el, post=None, every=1):
+    """Software-pipelined element loop: stage s of element e is issued in slot e + s; post(j) (pair j = elements 2j,
+    2j + 1) one slot after the last stage of element 2j + 1."""
+    ns = len(stages)
+    for k in range(n_el + ns + 2):
+        for s_i in range(ns):
+            e = k - s_i
+            if 0 <= e < n_el:
+                stages[s_i](e)
+        if post is not None:
+            jp = k - ns - 1
+            if jp >= 0 and jp % 2 == 1 and jp // 2 < n_el // 2:
+                post(jp // 2)
+
+
+def guide_epilogue_1(pa, hv, out_h, out_d):
+    """Energy net, layer 1: u = KD z1 in pa[0:16).  sg = 1 / (1 + 2^u); h' = u sg -> hv[e] (second accumulator);
+    silu'(z1) = sg (1 + (u - h') / KD) -> pa[e]; both packed to bf16: h' -> VGPRs out_h[0:8), silu' -> out_d[0:8)."""
+    ops, idx = [], {}
+    T = [TMP + i for i in range(7)]   # sg lives from stage A to stage G: 7 elements in flight
+
+    def add(key, text, deps=(), trans=False):
+        idx[key] = len(ops)
+        ops.append(Op(text, [(idx[k], md) for k, md in deps], trans))
+    add("K", "v_mov_b32_e32 v%d, 0x%x" % (VK, KD_INV_BITS))
+    st = [
+        lambda e: add(("A", e), "v_exp_f32_e32 v%d, v%d" % (T[e % 7], pa + e), [(("G", e - 7), 1)] if e >= 7 else [], True),
+        lambda e: add(("B", e), "v_add_f32_e32 v%d, 1.0, v%d" % (T[e % 7], T[e % 7]), [(("A", e), 3)]),
+        lambda e: add(("C", e), "v_rcp_f32_e32 v%d, v%d" % (T[e % 7], T[e % 7]), [(("B", e), 2)], True),
+        lambda e: add(("D", e), "v_mul_f32_e32 v%d, v%d, v%d" % (hv + e, pa + e, T[e % 7]), [(("C", e), 3)]),
+        lambda e: add(("E", e), "v_sub_f32_e32 v%d, v%d, v%d" % (pa + e, pa + e, hv + e), [(("D", e), 2)]),
+        lambda e: add(("F", e), "v_fmaak_f32 v%d, v%d, v%d, 0x3f800000" % (pa + e, pa + e, VK), [(("E", e), 2), ("K", 2)]),
+        lambda e: add(("G", e), "v_mul_f32_e32 v%d, v%d, v%d" % (pa + e, pa + e, T[e % 7]), [(("F", e), 2)]),
+    ]
+
+    def pack(j):
+        add(("PH", j), "v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (out_h + j, hv + 2 * j, hv + 2 * j + 1), [(("D", 2 * j), 2), (("D", 2 * j + 1), 2)])
+        add(("PD", j), "v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (out_d + j, pa + 2 * j, pa + 2 * j + 1), [(("G", 2 * j), 2), (("G", 2 * j + 1), 2)])
+    _pipeline(st, 16, pack)
+    return order_ops(ops)
+
+
+def guide_epilogue_2(pa, w3, out):
+    """Energy net, layer 2 and the output weight: u = KD z2 in pa[0:16), w3 tile in w3[0:16).
+    g2 = w3 silu'(z2) = w3 (sg + (u / KD) sg (1 - sg)) -> packed bf16 into AGPR fragments out = (frag0, frag1)."""
+    ops, idx = [], {}
+    T = [TMP + i for i in range(7)]   # sg lives from stage A to stage G: 7 elements in flight
+
+    def add(key, text, deps=(), trans=False):
+        idx[key] = len(ops)
+        ops.append(Op(text, [(idx[k], md) for k, md in deps], trans))
+    add("K", "v_mov_b32_e32 v%d, 0x%x" % (VK, KD_INV_BITS))
+    st = [
+        lambda e: add(("A", e), "v_exp_f32_e32 v%d, v%d" % (T[e % 7], pa + e), [(("G", e - 7), 1)] if e >= 7 else [], True),
+        lambda e: add(("B", e), "v_add_f32_e32 v%d, 1.0, v%d" % (T[e % 7], T[e % 7]), [(("A", e), 3)]),
+        lambda e: add(("C", e), "v_rcp_f32_e32 v%d, v%d" % (T[e % 7], T[e % 7]), [(("B", e), 2)], True),
+        lambda e: add(("D", e), "v_mul_f32_e32 v%d, v%d, v%d" % (pa + e, pa + e, VK), [("K", 2)]),
+        lambda e: add(("E", e), "v_mul_f32_e32 v%d, v%d, v%d" % (pa + e, pa + e, T[e % 7]), [(("D", e), 2), (("C", e), 3)]),
+        lambda e: add(("F", e), "v_fma_f32 v%d, -v%d, v%d, v%d" % (pa + e, pa + e, T[e % 7], pa + e), [(("E", e), 2)]),
+        lambda e: add(("G", e), "v_add_f32_e32 v%d, v%d, v%d" % (pa + e, pa + e, T[e % 7]), [(("F", e), 2)]),
+        lambda e: add(("H", e), "v_mul_f32_e32 v%d, v%d, v%d" % (pa + e, pa + e, w3 + e), [(("G", e), 2)]),
+    ]
+
+    def pack(j):
+        add(("P", j), "v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (pa + 2 * j, pa + 2 * j, pa + 2 * j + 1), [(("H", 2 * j), 2), (("H", 2 * j + 1), 2)])
+        add(("W", j), "v_accvgpr_write_b32 a%d, v%d" % (out[j // 4] + j % 4, pa + 2 * j), [(("P", j), 2)])
+    _pipeline(st, 16, pack)
+    return order_ops(ops)
+
+
+def guide_epilogue_3(pa, d1, out):
+    """g1 = (W2^T g2) * silu'(z1): pa[0:16) times the packed bf16 pairs in VGPRs d1[0:8) -> AGPR fragments out."""
+    ops, idx = [], {}
+    T = [TMP + i for i in range(4)]
+
+    def add(key, text, deps=(), trans=False):
+        idx[key] = len(ops)
+        ops.append(Op(text, [(idx[k], md) for k, md in deps], trans))
+    for j in range(8):
+        lo, hi = T[2 * (j % 2)], T[2 * (j % 2) + 1]
+        prev = [(("M1", j - 2), 1), (("M0", j - 2), 1)] if j >= 2 else []
+        add(("L", j), "v_lshlrev_b32_e32 v%d, 16, v%d" % (lo, d1 + j), prev)
+        add(("U", j), "v_and_b32_e32 v%d, 0xffff0000, v%d" % (hi, d1 + j), prev)
+        add(("M0", j), "v_mul_f32_e32 v%d, v%d, v%d" % (pa + 2 * j, pa + 2 * j, lo), [(("L", j), 2)])
+        add(("M1", j), "v_mul_f32_e32 v%d, v%d, v%d" % (pa + 2 * j + 1, pa + 2 * j + 1, hi), [(("U", j), 2)])
+        add(("P", j), "v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (pa + 2 * j, pa + 2 * j, pa + 2 * j + 1), [(("M0", j), 2), (("M1", j), 2)])
+        add(("W", j), "v_accvgpr_write_b32 a%d, v%d" % (out[j // 4] + j % 4, pa + 2 * j), [(("P", j), 2)])
+    return order_ops(ops)
+
+
 class Body:
     def __init__(self, cfg):
         self.c = cfg
@@ -190,10 +299,12 @@ class Body:
         self.frag_reader = {}
 
     # ------------------------------------------------------------------ program construction
-    def chain(self, acc, bfrags, tile=None, bias=None):
-        """A run of MFMAs accumulating into `acc` (string of 16 registers), one per B fragment."""
+    def chain(self, acc, bfrags, tile=None, bias=None, zero=False, wait=None):
+        """A run of MFMAs accumulating into `acc` (string of 16 registers), one per B fragment.  zero: the first one
+        starts from 0 instead of a preloaded bias tile; wait: name of an LDS read group its first MFMA depends on."""
         for i, b in enumerate(bfrags):
-            self.mf.append(dict(D=acc, B=b, tile=tile, bias=bias if i == 0 else None))
+            self.mf.append(dict(D=acc, B=b, tile=tile, bias=bias if i == 0 else None, zero=zero and i == 0,
+                                wait=wait if i == 0 else None))
 
     def new_tile(self, kind):
         t = dict(idx=len(self.tiles), buf=ACC[len(self.tiles) % 2], first=len(self.mf), kind=kind, ops=[], outs=[],
@@ -289,7 +400,48 @@ class Body:
         self.block_h(c.B_UP1, c.B_UP1 + H0, A(cat1), ste, c.N0)
         self.block_o(c.B_UP1 + 2 * H0, 0, hb[:c.K0], A(cat1), c.N0, False, cat1)
         self.chain(accL, A(cat1))
+        self.guide_first = len(self.mf)
+        if c.guide:
+            self.build_guide()
         self.nfrags = len(self.mf)
+
+    def build_guide(self):
+        """dE/dx of the energy net at (t, x, c) (engine_bf16.hip.inc, guide_grad): every register of the main net is
+        free by now except the last_block accumulator.
+          in1  = [t_emb_g | x | c] fragments   a[0:4*KS1)      (read from the park slots; ste is dead)
+          h1'  = KD silu(z1)                   v[HB ...)        16 fragments
+          d1   = silu'(z1) (bf16)              v[HB + 64 ...)   16 fragments
+          g2   = w3 silu'(z2)                  a[A_R1 ...)      16 fragments
+          g1   = (W2^T g2) d1                  a[A_R1 + 64 ...) 16 fragments
+          dE/dx accumulator                    a[A_R2 : A_R2 + 16)"""
+        c = self.c
+        in1 = [aq(A_STE + 4 * i) for i in range(c.GKS1)]
+        H1V, D1V = HB, HB + 4 * c.GK1
+        h1 = [vq(H1V + 4 * i) for i in range(c.GK1)]
+        G2A, G1A = A_R1, A_R1 + 4 * c.GK2
+        g2 = [aq(G2A + 4 * i) for i in range(c.GK2)]
+        g1 = [aq(G1A + 4 * i) for i in range(c.GK1)]
+        for n in range(c.GN1):
+            t = self.new_tile("g1")
+            A, Hv = t["buf"], t["buf"] + 16
+            t["bias"] = [(A, c.GB_1 + 32 * n)]
+            self.chain(self.acc_v(A), in1, t, bias=A, wait="in1" if n == 0 else None)
+            self.end_tile(t, guide_epilogue_1(A, Hv, H1V + 8 * n, D1V + 8 * n),
+                          [h1[2 * n], h1[2 * n + 1], vq(D1V + 8 * n), vq(D1V + 8 * n + 4)])
+        for n in range(c.GN2):
+            t = self.new_tile("g2")
+            A, W3 = t["buf"], t["buf"] + 16
+            t["bias"] = [(W3, c.GB_W3 + 32 * n), (A, c.GB_2 + 32 * n)]
+            self.chain(self.acc_v(A), h1, t, bias=A)
+            o = (G2A + 8 * n, G2A + 8 * n + 4)
+            self.end_tile(t, guide_epilogue_2(A, W3, o), [aq(o[0]), aq(o[1])])
+        for n in range(c.GN1):
+            t = self.new_tile("g3")
+            A = t["buf"]
+            self.chain(self.acc_v(A), g2, t, zero=True)
+            o = (G1A + 8 * n, G1A + 8 * n + 4)
+            self.end_tile(t, guide_epilogue_3(A, D1V + 8 * n, o), [aq(o[0]), aq(o[1])])
+        self.chain("a[%d:%d]" % (A_R2, A_R2 + 15), g1, zero=True)
 
     # ------------------------------------------------------------------ emission
     def emit(self, s):
@@ -473,6 +625,13 @@ class Body:
         bias_reads(-1)
         for n in range(min(PF, nf)):
             self.frag_read(n)
+        group_seq = {}
+        in1_gap = -1
+        if c.guide:
+            # the energy net's inputs replace the (dead) SiLU(t-embedding) fragments a dozen gaps before their first use
+            in1_gap = self.guide_first - 12
+            ste_names = set(aq(A_STE + 4 * i) for i in range(max(c.KS_T, c.GKS1)))
+            assert all(m["B"] not in ste_names for m in self.mf[in1_gap:self.guide_first]), "ste still in use"
         for g, m in enumerate(self.mf):
             self.cur_gap = g
             for op in forced.get(g, []):
@@ -493,8 +652,15 @@ class Body:
             if m["D"].startswith("a[") and not getattr(self, "_accl_ready", False):
                 need = max(need, accl_seq)
                 self._accl_ready = True
+            if m.get("wait"):
+                need = max(need, group_seq[m["wait"]])
             self.lds_wait(need)
-            self.emit("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (m["D"], qslot(g), m["B"], m["D"]))
+            self.emit("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (m["D"], qslot(g), m["B"], "0" if m.get("zero") else m["D"]))
+            if g == in1_gap:
+                park = [c.PARK_G + i for i in range(c.GKT)] + [c.PARK_X] + [c.PARK_G + c.GKT + i for i in range(c.KS_C)]
+                for i, slot in enumerate(park):
+                    self.emit("ds_read_b128 %s, %%[park] offset:%d" % (aq(A_STE + 4 * i), slot * 1024))
+                    group_seq["in1"] = self.lds_issue()
             if g + PF < nf:
                 if (g + PF) % c.cf == 0:
                     self.dma_tick(flush=True)     # pieces of the previous chunk must be issued before the next hand-off
@@ -517,6 +683,9 @@ class Body:
         self.emit("s_nop 7")
         for i in range(8):
             self.emit("v_accvgpr_read_b32 %%[o%d], a%d" % (i, A_ACCL + i))
+        if c.guide:
+            for i in range(8):
+                self.emit("v_accvgpr_read_b32 %%[o%d], a%d" % (8 + i, A_R2 + i))
         return self.out
 
 
@@ -538,16 +707,19 @@ def function_text(cfg):
         cfg.name, b.nfrags, len(lines), ", ".join("%s %d" % kv for kv in sorted(cnt.items(), key=lambda kv: -kv[1])[:12])))
     o.append("struct AsmBody_%s {" % cfg.name)
     o.append("  static constexpr bool ON = true;")
-    o.append("  static constexpr int FRAGS = %d, NSLOT = %d, CF = %d, KS_T0 = %d, PARK_FRAGS = %d, INSTRUCTIONS = %d;" % (
-        b.nfrags, cfg.nslot, cfg.cf, ntc, ntc + 1, len(lines)))
-    o.append("  // park: LDS address of this lane's PARK_FRAGS input fragments ([t_emb | c_emb] then x), 1 KiB apart")
+    o.append("  static constexpr int FRAGS = %d, NSLOT = %d, CF = %d, KS_T0 = %d, PARK_FRAGS = %d, PARK_X = %d, PARK_G = %d, "
+             "OUTPUTS = %d, INSTRUCTIONS = %d;" % (b.nfrags, cfg.nslot, cfg.cf, ntc, cfg.PARK_FRAGS, cfg.PARK_X, cfg.PARK_G,
+                                                  16 if cfg.guide else 8, len(lines)))
+    o.append("  // park: LDS address of this lane's PARK_FRAGS input fragments, 1 KiB apart: [t_emb | c_emb], x at PARK_X, and for")
+    o.append("  // guided bodies from PARK_G the energy net's t_emb fragments, then the raw condition fragments.")
+    o.append("  // o[0:8) = KD * net; guided bodies: o[8:16) = dE/dx of the energy net")
     o.append("  static __device__ __forceinline__ void run(uint32_t park, uint32_t voff, uint32_t rd, uint32_t bias, "
              "i32x4 rsrc, uint32_t ldsw, uint32_t wid, float* o) {")
     o.append("    uint32_t soff;")
     o.append("    asm volatile(")
     for l in lines:
         o.append('      "%s\\n\\t"' % l)
-    outs = ", ".join('[o%d] "=v"(o[%d])' % (i, i) for i in range(8)) + ', [soff] "=&s"(soff)'
+    outs = ", ".join('[o%d] "=v"(o[%d])' % (i, i) for i in range(16 if cfg.guide else 8)) + ', [soff] "=&s"(soff)'
     ins = '[park] "v"(park), [voff] "v"(voff), [rd] "v"(rd), [bias] "v"(bias), [rsrc] "s"(rsrc), [ldsw] "s"(ldsw), [wid] "s"(wid)'
     clob = ['"memory"', '"scc"']
     clob += ['"v%d"' % i for i in range(NV)]
@@ -565,6 +737,7 @@ CONFIGS = [
     # one k-step; the condition embedding is computed outside the body)
     Cfg("cond", 16, 32, 32, 32, 128, 512, 256, 128),
     Cfg("uncond", 16, 0, 0, 32, 32, 512, 256, 128),
+    Cfg("cond_guided", 16, 32, 32, 32, 128, 512, 256, 128, guide=(32, 256, 256)),
 ]
 
 if __name__ == "__main__":

@@ -2,6 +2,8 @@
 // Per iteration: 16 x v_mfma_f32_32x32x16_bf16 (A from LDS via ds_read_b128, B in registers) and NP DMA pieces,
 // either clustered at the start of the iteration (MODE 0) or one piece every 16/NP MFMAs (MODE 1);
 // MODE 2: A operands stay in registers (no LDS reads).
+// MODE 3: like MODE 1, but the refill goes through registers: buffer_load_dwordx4 -> VGPRs, and one iteration later
+// ds_write_b128 -> LDS (4 staging quads per wave).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -23,11 +25,13 @@ __global__ __launch_bounds__(256, 1) void k(const char* stream, int iters, float
   for (int e = 0; e < 8; ++e) b[e] = (__bf16)(0.01f * (lane + e));
   bf16x8 areg = b;
   const char* rd = lds + lane * 16;
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  i32x4 stg[4] = {};
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #pragma clang loop unroll(disable)
   for (int it = 0; it < iters; ++it) {
     const int slot = (it & 3) * 16384, ch = (it % 200) * 16384;
-    if (NP > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+    if (NP > 0 && MODE != 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
     if (MODE == 0) {
       if (NP >= 1) PIECE(0, slot + wave * 4096, ch);
       if (NP >= 2) PIECE(1, slot + wave * 4096, ch);
@@ -39,7 +43,14 @@ __global__ __launch_bounds__(256, 1) void k(const char* stream, int iters, float
       bf16x8 a = MODE == 2 ? areg : *(const bf16x8*)(rd + ((it + 1) & 3) * 16384 + m * 1024);
       if (m & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc1, 0, 0, 0);
       else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
-      if (MODE != 0 && NP > 0) {
+      if (MODE == 3) {
+        // write the piece loaded one iteration ago, then reload its staging quad
+        char* wr = lds + slot + wave * 4096 + lane * 16;
+#define RT(q, mm) if (m == (mm) && NP > (q)) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP - 1) : "memory"); \
+          *(i32x4*)(wr + (q) * 1024) = stg[q]; \
+          stg[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + (q) * 1024, ch, 0); }
+        RT(0, 1) RT(1, 5) RT(2, 9) RT(3, 13)
+      } else if (MODE != 0 && NP > 0) {
         if (m == 1 && NP >= 1) PIECE(0, slot + wave * 4096, ch);
         if (m == 5 && NP >= 2) PIECE(1, slot + wave * 4096, ch);
         if (m == 9 && NP >= 3) PIECE(2, slot + wave * 4096, ch);
@@ -75,5 +86,6 @@ int main() {
   run<0, 0>(d, out, dc); run<1, 0>(d, out, dc); run<2, 0>(d, out, dc); run<4, 0>(d, out, dc);
   run<1, 1>(d, out, dc); run<2, 1>(d, out, dc); run<4, 1>(d, out, dc);
   run<0, 2>(d, out, dc); run<2, 2>(d, out, dc); run<4, 2>(d, out, dc);
+  run<2, 3>(d, out, dc); run<4, 3>(d, out, dc);
   return 0;
 }
