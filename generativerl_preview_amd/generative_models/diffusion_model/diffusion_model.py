@@ -89,14 +89,13 @@ class DiffusionModel(nn.Module):
             assert hasattr(self, "solver"), "solver must be specified in config or solver_config"
             solver = self.solver
         function, function_type = self._function(_guidance_scale)
-        if with_grad and not (isinstance(solver, ODESolver) and not isinstance(solver, DPMSolver)):
-            raise NotImplementedError("differentiable sampling (with_grad=True) is implemented for ODESolver only")
         if isinstance(solver, DPMSolver):
             # diffusion_model.py:255-279 / energy_conditional_diffusion_model.py:370-405
             assert t_span is None, "DPMSolver does not support t_span argument assignment"
             noise_fn, data_fn = self._dpm_functions(_guidance_scale)
             data = solver.integrate(diffusion_process=self.diffusion_process, noise_function=noise_fn,
-                                    data_prediction_function=data_fn, x=x, condition=condition, save_intermediate=True)
+                                    data_prediction_function=data_fn, x=x, condition=condition, save_intermediate=True,
+                                    with_grad=with_grad)
             if _final_only:
                 data = data[-1]
         elif isinstance(solver, ODESolver):
@@ -110,7 +109,8 @@ class DiffusionModel(nn.Module):
                 reverse_diffusion_function=self.reverse_diffusion_process.diffusion,
                 reverse_diffusion_squared_function=self.reverse_diffusion_process.diffusion_squared)
             data = solver.integrate(drift=sde.drift, diffusion=sde.diffusion, x0=x, t_span=t_span,
-                                    noise_increments=noise_increments, return_trajectory=not _final_only)
+                                    noise_increments=noise_increments, return_trajectory=not _final_only,
+                                    with_grad=with_grad)
         else:
             raise NotImplementedError("Solver type {} is not implemented".format(type(solver).__name__))
         if _final_only:

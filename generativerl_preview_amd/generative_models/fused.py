@@ -103,7 +103,7 @@ class FusedDrift:
         return m.plan.sample(m.packed(dtype), x0, self.condition, table, dW=increments, guidance=g_plan,
                              guidance_packed=g_packed, trajectory_slots=trajectory_slots, dtype=dtype)
 
-    def integrate_with_grad(self, x0, table):
+    def integrate_with_grad(self, x0, table, increments=None):
         """Differentiable Euler chain (``with_grad=True``): the fp32 trajectory (n_steps + 1, R, D) with a grad_fn whose
         backward walks the chain in the library (grlhip_sample_ode_backward) -- gradients reach the model's parameters
         and x0, not the condition.  Every step of ``table`` must emit slot k + 1 with lerp 1.
@@ -112,7 +112,7 @@ class FusedDrift:
         backward is the unguided chain rule along the guided trajectory, with no gradient to the energy net."""
         named = self.model._named()
         params = [named[n] for n, _ in self.model.plan.params]
-        return _DifferentiableOde.apply(self, table, x0, *params)
+        return _DifferentiableOde.apply(self, table, increments, x0, *params)
 
     # a FusedDrift is also callable like the reference closure (one fused launch of a single step
     # evaluation is not provided; the solvers never call it)
@@ -122,14 +122,14 @@ class FusedDrift:
 
 class _DifferentiableOde(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, drift, table, x0, *params):
+    def forward(ctx, drift, table, increments, x0, *params):
         m = drift.model
         n = table.shape[0]
         g_plan = g_packed = None
         if drift.guidance is not None:
             g_plan, g_packed = drift.guidance.plan, drift.guidance.packed(L.F32)
-        _, traj = m.plan.sample(m.packed(L.F32), x0, drift.condition, table, guidance=g_plan, guidance_packed=g_packed,
-                                trajectory_slots=n + 1, dtype=L.F32)
+        _, traj = m.plan.sample(m.packed(L.F32), x0, drift.condition, table, dW=increments, guidance=g_plan,
+                                guidance_packed=g_packed, trajectory_slots=n + 1, dtype=L.F32)
         ctx.drift, ctx.table = drift, table
         ctx.save_for_backward(traj)
         return traj
@@ -149,7 +149,7 @@ class _DifferentiableOde(torch.autograd.Function):
                 grads.append(flat[off:off + p.numel()].view(p.shape))
             else:
                 grads.append(None)
-        return (None, None, gx0 if ctx.needs_input_grad[2] else None, *grads)
+        return (None, None, None, gx0 if ctx.needs_input_grad[3] else None, *grads)
 
 
 class AffineModelFn:

@@ -64,9 +64,11 @@ class DPMSolver:
         raise ValueError("'order' must be '1' or '2' or '3'.")
 
     def integrate(self, diffusion_process, noise_function, data_prediction_function, x, condition=None,
-                  steps: int = None, save_intermediate: bool = False):
+                  steps: int = None, save_intermediate: bool = False, with_grad: bool = False):
         """dpm_solver.py:83-905.  ``x``: (B, ...) device tensor; returns the final state, or the stacked states
-        (len(orders) + 1, B, ...) with ``save_intermediate=True``."""
+        (len(orders) + 1, B, ...) with ``save_intermediate=True``.  ``with_grad`` (the reference simply does not wrap
+        the call in ``no_grad``, diffusion_model.py:261-279): the stages run host-driven with autograd on -- every model
+        evaluation is the differentiable HIP forward (backward = grlhip_net_backward), the stage algebra is torch."""
         steps = steps if steps is not None else self.steps if self.steps is not None else 20
         if self.method != "singlestep":
             raise NotImplementedError("DPMSolver method '%s' (the reference's 'singlestep_fixed' fails on an unbound "
@@ -156,10 +158,10 @@ class DPMSolver:
         orders = self.get_orders_for_singlestep_solver(steps=steps, order=self.order)
         ts = self.get_time_steps(t_T=t_T, t_0=t_0, N=steps)
         fn = data_prediction_function if plus else noise_function
-        if self.fused and hasattr(fn, "coefficients") and (max(orders) <= 2 or high) and x.is_cuda and x.dim() == 2:
+        if not with_grad and self.fused and hasattr(fn, "coefficients") and (max(orders) <= 2 or high) and x.is_cuda and x.dim() == 2:
             return self._integrate_fused(dp, fn, x, condition, orders, ts, save_intermediate)
         x_list = [x.clone()] if save_intermediate else None
-        with torch.no_grad():
+        with torch.enable_grad() if with_grad else torch.no_grad():
             i = 0
             for o in orders:
                 s, t = ts[i], ts[i + o]

@@ -64,7 +64,7 @@ class SDESolver:
         return emit, lerp, emit2, lerp2, extra
 
     def integrate(self, drift, diffusion, x0, t_span, logqp=False, adaptive=False, noise_increments=None,
-                  return_trajectory=True):
+                  return_trajectory=True, with_grad=False):
         if self.sde_solver != "euler" or self.sde_noise_type != "diagonal" or self.sde_type != "ito" or adaptive or logqp:
             raise NotImplementedError("only the fixed-step diagonal-Ito Euler-Maruyama scheme is implemented")
         if not isinstance(drift, FusedDrift):
@@ -81,6 +81,16 @@ class SDESolver:
                                                 for k in range(n)])
             else:
                 noise_increments = torch.randn(n, *flat.shape, device=flat.device) * dts.sqrt().to(flat.device)[:, None, None]
+        if with_grad:
+            # differentiable: keep every inner state (slot k + 1 after inner step k), walk the chain backwards in the
+            # library (the increments are constants of the chain), interpolate the requested outputs in torch
+            every = drift.table(t0s, dts, torch.arange(1, n + 1, dtype=torch.float32), torch.ones(n))
+            inner = drift.integrate_with_grad(flat, every, noise_increments.reshape(n, B, -1))
+            self.nfe_drift = self.nfe_diffusion = n
+            out = [inner[0]] + [inner[s] + w * (inner[s + 1] - inner[s]) for _, s, w in outs]
+            if not return_trajectory:
+                return out[-1].reshape(x0.shape)
+            return torch.stack(out, 0).reshape(t_span.shape[0], *x0.shape)
         table = drift.table(t0s, dts, emit, lerp, emit2, lerp2)
         final, traj = drift.integrate(flat, table, noise_increments.reshape(n, B, -1),
                                       trajectory_slots=len(t_span) if return_trajectory else 0)
