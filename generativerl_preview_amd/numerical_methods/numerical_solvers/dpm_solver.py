@@ -158,7 +158,7 @@ class DPMSolver:
         orders = self.get_orders_for_singlestep_solver(steps=steps, order=self.order)
         ts = self.get_time_steps(t_T=t_T, t_0=t_0, N=steps)
         fn = data_prediction_function if plus else noise_function
-        if not with_grad and self.fused and hasattr(fn, "coefficients") and (max(orders) <= 2 or high) and x.is_cuda and x.dim() == 2:
+        if not with_grad and self.fused and hasattr(fn, "coefficients") and x.is_cuda and x.dim() == 2:
             return self._integrate_fused(dp, fn, x, condition, orders, ts, save_intermediate)
         x_list = [x.clone()] if save_intermediate else None
         with torch.enable_grad() if with_grad else torch.no_grad():
@@ -189,17 +189,17 @@ class DPMSolver:
         return traj if save_intermediate else final
 
     def stage_table(self, dp, fn, orders, ts, save_intermediate=True):
-        """Orders 1-2, and order 3 with solver_type "dpm_solver" (its last stage needs only the first model value; the
-        "taylor" form also needs the second and stays host-driven): every stage is
-        `m = cn net + cx x + cg dE/dx; x <- P x + Q xs + R m + W ms` (include/grlhip.h, grlhip_sample_stages); the same
+        """Orders 1-3, both solver types: every stage is
+        `m = cn net + cx x + cg dE/dx; x <- P x + Q xs + R m + W ms + W2 ms2` (include/grlhip.h, grlhip_sample_stages;
+        ms2, the second saved model value, is only needed by the last stage of the "taylor" form of order 3); the same
         scalars as the host-driven path, tabulated once."""
         plus, high = self.use_dpm_solver_plus_plus, self.default_high_order_solvers
         lam, la, sig = dp.HalfLogSNR, dp.log_scale, dp.std
         rows = []
 
-        def stage(tau, P, Q, R, W, save, emit):
+        def stage(tau, P, Q, R, W, save, emit, W2=0.0):
             cn, cx, cg = fn.coefficients(tau)
-            rows.append([float(tau), float(P), float(Q), float(R), float(W), cn, cx, cg, float(save), float(emit), 0.0, 0.0])
+            rows.append([float(tau), float(P), float(Q), float(R), float(W), cn, cx, cg, float(save), float(emit), float(W2), 0.0])
 
         i = 0
         for k, o in enumerate(orders):
@@ -220,15 +220,32 @@ class DPMSolver:
                     c2 = r2 / r1 * a2 * (p12 / (r2 * h) + 1.0)            # x2 = .. + c2 (m1 - m)
                     c3 = (1.0 / r2) * at * (p1 / h + 1.0)                  # x_t = .. + c3 (m2 - m)
                     stage(s, sig(s1) / sig(s), 0.0, -(torch.exp(la(s1)) * torch.expm1(-r1 * h)), 0.0, 1, -1)
-                    stage(s1, 0.0, sig(s2) / sig(s), c2, -(a2 * p12) - c2, 0, -1)
-                    stage(s2, 0.0, keep, c3, -lead - c3, 0, emit)
+                    stage(s1, 0.0, sig(s2) / sig(s), c2, -(a2 * p12) - c2, 0 if high else 2, -1)
+                    if high:
+                        stage(s2, 0.0, keep, c3, -lead - c3, 0, emit)
+                    else:
+                        # x_t = keep x - lead m + at p2 D1 - at p3 D2 with D1, D2 linear in (m1 - m), (m2 - m)
+                        p2 = p1 / h + 1.0
+                        p3 = p2 / h - 0.5
+                        k1 = at * p2 * (r2 / r1) / (r2 - r1) + at * p3 * 2.0 / (r1 * (r2 - r1))     # of (m1 - m)
+                        k2 = -at * p2 * (r1 / r2) / (r2 - r1) - at * p3 * 2.0 / (r2 * (r2 - r1))    # of (m2 - m)
+                        stage(s2, 0.0, keep, k2, -lead - k1 - k2, 0, emit, W2=k1)
                 else:
                     p12, p1 = torch.expm1(r2 * h), torch.expm1(h)
                     c2 = r2 / r1 * sig(s2) * (p12 / (r2 * h) - 1.0)        # x2 = .. - c2 (m1 - m)
                     c3 = (1.0 / r2) * sig(t) * (p1 / h - 1.0)              # x_t = .. - c3 (m2 - m)
                     stage(s, torch.exp(la(s1) - la(s)), 0.0, -(sig(s1) * torch.expm1(r1 * h)), 0.0, 1, -1)
-                    stage(s1, 0.0, torch.exp(la(s2) - la(s)), -c2, -(sig(s2) * p12) + c2, 0, -1)
-                    stage(s2, 0.0, keep, -c3, -lead + c3, 0, emit)
+                    stage(s1, 0.0, torch.exp(la(s2) - la(s)), -c2, -(sig(s2) * p12) + c2, 0 if high else 2, -1)
+                    if high:
+                        stage(s2, 0.0, keep, -c3, -lead + c3, 0, emit)
+                    else:
+                        # x_t = keep x - lead m - sig(t) p2 D1 - sig(t) p3 D2
+                        st_ = sig(t)
+                        p2 = p1 / h - 1.0
+                        p3 = p2 / h - 0.5
+                        k1 = -st_ * p2 * (r2 / r1) / (r2 - r1) + st_ * p3 * 2.0 / (r1 * (r2 - r1))   # of (m1 - m)
+                        k2 = st_ * p2 * (r1 / r2) / (r2 - r1) - st_ * p3 * 2.0 / (r2 * (r2 - r1))    # of (m2 - m)
+                        stage(s2, 0.0, keep, k2, -lead - k1 - k2, 0, emit, W2=k1)
             else:
                 r1 = (lam(ts[i + 1]) - lam(s)) / h
                 s1 = dp.InverseHalfLogSNR(lam(s) + r1 * h).reshape(-1)[0]

@@ -180,18 +180,19 @@ int grlhip_sample_sde(const grlhip_plan* plan, const void* packed, int dtype,
                       int32_t n_steps, int64_t rows, float* out_final, float* out_traj,
                       void* workspace, size_t workspace_bytes, void* stream);
 
-/* Replaces: DPMSolver.integrate, method "singlestep", orders 1-2 and order 3 with solver_type "dpm_solver"
- * (grl/numerical_methods/numerical_solvers/dpm_solver.py:250-391,854-904) and any other solver whose step is a
+/* Replaces: DPMSolver.integrate, method "singlestep", orders 1-3, both solver types
+ * (grl/numerical_methods/numerical_solvers/dpm_solver.py:250-523,854-904) and any other solver whose step is a
  * sequence of STAGES, each one evaluation of the network (and energy gradient) followed by an affine update with
- * one saved state and one saved model output.  stage_table[n_stages][GRLHIP_COEF_STRIDE], a HOST-computed DEVICE
+ * one saved state and two saved model outputs.  stage_table[n_stages][GRLHIP_COEF_STRIDE], a HOST-computed DEVICE
  * table with the layout
  *   [0] tau   time fed to the network(s) at this stage
  *   [5] cn, [6] cx, [7] cg     m = cn*net(tau,x,c) + cx*x + cg*dE/dx(tau,x,c)   (the solver's "model" output: the
  *                              head conversion and the energy guidance folded into three scalars)
- *   [1] P, [2] Q, [3] R, [4] W x_new = P*x + Q*xs + R*m + W*ms
- *   [8] save  != 0: afterwards xs = x (the state BEFORE the update), ms = m       (xs = ms = 0 initially)
+ *   [1] P, [2] Q, [3] R, [4] W, [10] W2    x_new = P*x + Q*xs + R*m + W*ms + W2*ms2
+ *   [8] save  1: afterwards xs = x (the state BEFORE the update), ms = m;  2: afterwards ms2 = m;  0: nothing
+ *             (xs = ms = ms2 = 0 initially)
  *   [9] emit  >= 0: out_traj[emit] = x_new (stored as float; only if out_traj != NULL; slot 0 = x0)
- *   [10], [11] reserved (0).
+ *   [11] reserved (0).
  * One call runs every stage of every row (one launch on the fused bf16 path). */
 int grlhip_sample_stages(const grlhip_plan* plan, const void* packed, int dtype,
                          const grlhip_plan* guidance, const void* guidance_packed,

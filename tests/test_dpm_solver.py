@@ -138,7 +138,8 @@ def test_gpu_dpm_solver_vs_reference_golden(name):
 
 @pytest.mark.gpu
 def test_gpu_fused_stages_equal_host_driven_stages_and_bf16_runs_in_the_persistent_kernel():
-    """Orders <= 2 go through grlhip_sample_stages (one call; the persistent bf16 integrator for the QGPO shapes):
+    """Every order and solver type goes through grlhip_sample_stages (one call; the persistent bf16 integrator for the
+    QGPO shapes; the taylor form of order 3 uses the second saved model value):
     same result as the host-driven evaluation in fp32, within the bf16 tolerance of the oracle in bf16."""
     from generativerl_preview_amd import _lib as L
     from generativerl_preview_amd.numerical_methods.numerical_solvers import DPMSolver
@@ -152,21 +153,20 @@ def test_gpu_fused_stages_equal_host_driven_stages_and_bf16_runs_in_the_persiste
     orig = engine.NetPlan.sample_stages
     engine.NetPlan.sample_stages = lambda self, *a, **k: (calls.append(k.get("dtype")), orig(self, *a, **k))[1]
     try:
-        for typ, order in (("dpm_solver++", 2), ("dpm_solver", 2), ("dpm_solver++", 3), ("dpm_solver", 3)):
-            args = dict(order=order, device=DEV, steps=17, type=typ)
+        for typ, order, stype in (("dpm_solver++", 2, "dpm_solver"), ("dpm_solver", 2, "dpm_solver"), ("dpm_solver++", 3, "dpm_solver"),
+                                  ("dpm_solver", 3, "dpm_solver"), ("dpm_solver", 3, "taylor"), ("dpm_solver++", 3, "taylor"),
+                                  ("dpm_solver", 2, "taylor")):
+            args = dict(order=order, device=DEV, steps=17, type=typ, solver_type=stype)
+            n_before = len(calls)
             fused = m.sample_forward_process(x_0=x0.to(DEV), condition=cond.to(DEV), guidance_scale=1.0,
                                              solver_config=dict(type="DPMSolver", args=args))
-            assert len(calls) >= 1
+            assert len(calls) == n_before + 1   # ONE grlhip_sample_stages call, the taylor form of order 3 included
             solver = DPMSolver(**args)
             solver.fused = False
             nf, df = m._dpm_functions(1.0)
             host = solver.integrate(m.diffusion_process, nf, df, x0.to(DEV), cond.to(DEV), save_intermediate=True)
             assert solver.nfe == 17
-            close(fused.cpu(), host.cpu(), 2e-5, "fused vs host-driven %s order %d" % (typ, order), rel="++" in typ)
-        n_fused = len(calls)
-        m.sample_forward_process(x_0=x0.to(DEV), condition=cond.to(DEV), guidance_scale=1.0, solver_config=dict(
-            type="DPMSolver", args=dict(order=3, device=DEV, steps=9, type="dpm_solver", solver_type="taylor")))
-        assert len(calls) == n_fused   # the taylor form of order 3 needs two saved model values: host-driven
+            close(fused.cpu(), host.cpu(), 2e-5, "fused vs host-driven %s order %d %s" % (typ, order, stype), rel="++" in typ)
         # bf16: the persistent integrator, on the O(1) noise-prediction form (the guided data-prediction form of
         # dpm_solver++ diverges as written in the reference, see _rel)
         path, mt = O.Path(cfg["path"]), cfg["model"]["type"]
@@ -188,10 +188,12 @@ def test_gpu_fused_stages_equal_host_driven_stages_and_bf16_runs_in_the_persiste
         engine.NetPlan.sample_stages = orig
 
 
-@pytest.mark.parametrize("name,typ,order,steps", [("small_vp_noise", "dpm_solver", 2, 17), ("small_vp_velocity", "dpm_solver++", 2, 10),
-                                                  ("small_energy", "dpm_solver", 3, 10), ("small_energy", "dpm_solver++", 3, 9),
-                                                  ("small_vp_score", "dpm_solver++", 1, 6)])
-def test_stage_table_reproduces_the_solver_on_the_cpu(name, typ, order, steps):
+@pytest.mark.parametrize("name,typ,order,steps,stype", [
+    ("small_vp_noise", "dpm_solver", 2, 17, "dpm_solver"), ("small_vp_velocity", "dpm_solver++", 2, 10, "dpm_solver"),
+    ("small_energy", "dpm_solver", 3, 10, "dpm_solver"), ("small_energy", "dpm_solver++", 3, 9, "dpm_solver"),
+    ("small_vp_score", "dpm_solver++", 1, 6, "dpm_solver"), ("small_vp_noise", "dpm_solver", 3, 10, "taylor"),
+    ("small_energy", "dpm_solver++", 3, 9, "taylor"), ("small_vp_velocity", "dpm_solver", 2, 8, "taylor")])
+def test_stage_table_reproduces_the_solver_on_the_cpu(name, typ, order, steps, stype):
     """Host logic of the fused path, no GPU: the stage table DPMSolver hands to grlhip_sample_stages, executed by a
     ten-line interpreter over the ORACLE's network (and energy gradient), gives the oracle's DPM-Solver trajectory."""
     from generativerl_preview_amd.numerical_methods.numerical_solvers import DPMSolver
@@ -199,7 +201,7 @@ def test_stage_table_reproduces_the_solver_on_the_cpu(name, typ, order, steps):
     sd = gu.weights(name)
     gen = torch.Generator().manual_seed(2)
     x0, cond = torch.randn(9, 6, generator=gen), torch.randn(9, 17, generator=gen)
-    solver = DPMSolver(order=order, device="cpu", steps=steps, type=typ)
+    solver = DPMSolver(order=order, device="cpu", steps=steps, type=typ, solver_type=stype)
     gs = 1.0 if kind == "energy" else None
     noise_fn, data_fn = m._dpm_functions(gs)
     fn = data_fn if typ == "dpm_solver++" else noise_fn
@@ -207,16 +209,18 @@ def test_stage_table_reproduces_the_solver_on_the_cpu(name, typ, order, steps):
     ts = solver.get_time_steps(t_T=float(m.diffusion_process.t_max), t_0=0.00001, N=steps)
     table = solver.stage_table(m.diffusion_process, fn, orders, ts)
     assert table.shape == (steps, 12) and int(table[:, 9].max()) == len(orders)
-    x, xs, ms, traj = x0, torch.zeros_like(x0), torch.zeros_like(x0), [x0]
+    x, xs, ms, ms2, traj = x0, torch.zeros_like(x0), torch.zeros_like(x0), torch.zeros_like(x0), [x0]
     for row in table.tolist():
-        tau, P, Q, R, W, cn, cx, cg, save, emit = row[:10]
+        tau, P, Q, R, W, cn, cx, cg, save, emit, W2 = row[:11]
         t = torch.full((x.shape[0],), tau)
         mval = cn * O.intrinsic_forward(sd, t, x, cond) + cx * x
         if kind == "energy":
             mval = mval + cg * O.energy_guidance(sd, t, x, cond, 1.0)
-        xn = P * x + Q * xs + R * mval + W * ms
-        if save:
+        xn = P * x + Q * xs + R * mval + W * ms + W2 * ms2
+        if save == 1:
             xs, ms = x, mval
+        elif save == 2:
+            ms2 = mval
         x = xn
         if emit >= 0:
             traj.append(x)
@@ -229,7 +233,7 @@ def test_stage_table_reproduces_the_solver_on_the_cpu(name, typ, order, steps):
         net = lambda t, y: O.intrinsic_forward(sd, t, y, cond)  # noqa: E731
         nf = lambda t, y: O.noise_head(mt, path, net(t, y), t, y)  # noqa: E731
         df = lambda t, y: O.data_head(mt, path, net(t, y), t, y)  # noqa: E731
-    want = O.dpm_solver_integrate(path, nf, df, x0, steps=steps, order=order, type=typ)
+    want = O.dpm_solver_integrate(path, nf, df, x0, steps=steps, order=order, type=typ, solver_type=stype)
     got = torch.stack(traj)
     assert got.shape == want.shape
     close(got.detach(), want.detach(), 2e-4, "stage table vs oracle solver", rel=_rel(name, typ))
