@@ -337,6 +337,43 @@ def test_bf16_generic_shapes_run_on_the_batch_engine(name, rows, steps):
     assert float((got - exact).abs().max()) > 0.0, "bf16 path returned the fp32 result bit for bit: not the bf16 kernels"
 
 
+@pytest.mark.parametrize("x_dim,c_dim,guided", [(1, 5, False), (16, 32, True), (16, 33, False), (8, 16, True), (5, 67, False),
+                                                 (16, None, False), (1, None, False)])
+def test_bf16_fused_kernel_at_the_edges_of_its_shape_classes(x_dim, c_dim, guided):
+    """Action widths 1 and 16, observation widths around the 16-column k-steps (16, 32, 33, 67), unconditional: the padded
+    shape classes of the fused integrator against the oracle.  Seeded (untrained) weights and 8 steps, so states grow:
+    the comparison is relative to max|ref| (2e-2) -- it checks the padding / run-time width plumbing, not the bf16 budget."""
+    import generativerl_preview_amd as G
+    cfg = dict(gl.diffusion_cfg(x_dim, gl.VP, "noise_function", [512, 256, 128], c_dim, energy=guided), device=DEV)
+    torch.manual_seed(100 * x_dim + (c_dim or 0))
+    m = (G.EnergyConditionalDiffusionModel if guided else G.DiffusionModel)(cfg).to(DEV)
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if "last_block" in k:
+                p.mul_(0.1)
+    m.model.compute_dtype = L.BF16
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    rows = 300
+    gen = torch.Generator().manual_seed(3)
+    x0 = torch.randn(rows, x_dim, generator=gen)
+    cond = torch.randn(rows, c_dim, generator=gen) if c_dim else None
+    t_span = torch.linspace(0.0, 1.0, 9)
+    kw = dict(t_span=t_span, x_0=x0.to(DEV))
+    if c_dim:
+        kw["condition"] = cond.to(DEV)
+    if guided:
+        kw["guidance_scale"] = 2.0
+    got = m.sample(**kw).cpu()
+    fk = m.model.plan.fused_kernel(m.energy_guidance.model.plan if guided else None)
+    assert "k_sample_bf16" in fk and (("energy-guided" in fk) == guided), fk
+    okw = dict(guidance_scale=2.0) if guided else {}
+    want = O.sample_forward_process(sd, cfg, "energy" if guided else "diffusion", t_span, x_0=x0, condition=cond, **okw)[-1]
+    close(got, want, tol=BF16_TOL, what="bf16 class edge x%d c%s guided %d" % (x_dim, c_dim, guided), rel=True)
+    m.model.compute_dtype = L.F32
+    exact = m.sample(**kw).cpu()
+    close(exact, want, tol=TOL, what="fp32 class edge x%d c%s guided %d" % (x_dim, c_dim, guided), rel=True)
+
+
 def test_bf16_mixed_pair_is_rejected():
     """small net (batch engine, fp32-layout image) + the [256,256] energy net (fused-kernel fragment image): no
     bf16 kernel takes that pair; the library must say so instead of reading an image in the wrong layout."""
@@ -445,6 +482,24 @@ def test_weighted_rows_backward_and_trainable_fourier():
     for k, p in m.named_parameters():
         if k.startswith("model."):
             close(p.grad, grads[k], tol=3e-4, what=k, rel=True)
+
+
+def test_torch_compile_wrapped_model_is_usable():
+    """The reference's algorithms wrap their policies in torch.compile (grl/algorithms/qgpo.py:350, base.py:130; its own
+    test grl/unittest/generative_models/diffusion_model/test_diffusion_model.py:86-88 calls the loss and sample methods of
+    the wrapper).  The wrapper forwards attribute access to the module, so the HIP path is reached unchanged."""
+    kind, cfg, m = um.build("small_vp_noise", DEV)
+    cm = torch.compile(m)
+    g = gu.load("model_small_vp_noise.npz")
+    x, cond = cu(g["x"]), cu(g["cond"])
+    a = m.score_matching_loss(x, cond, weighting_scheme="vanilla", t=cu(g["sm_t"]), noise=cu(g["sm_eps"]))
+    b = cm.score_matching_loss(x, cond, weighting_scheme="vanilla", t=cu(g["sm_t"]), noise=cu(g["sm_eps"]))
+    assert torch.equal(a.detach(), b.detach())
+    b.backward()
+    assert all(p.grad is not None for k, p in m.named_parameters() if k.startswith("model.") and not k.endswith("t_encoder.W"))
+    ts = torch.linspace(0, 1, 6)
+    assert torch.equal(m.sample(t_span=ts, x_0=x[:8], condition=cond[:8]), cm.sample(t_span=ts, x_0=x[:8], condition=cond[:8]))
+    assert set(cm.state_dict()) == set("_orig_mod." + k for k in m.state_dict()) or set(cm.state_dict()) == set(m.state_dict())
 
 
 def test_gradients_are_bit_reproducible():
