@@ -28,9 +28,10 @@ int main(int argc, char** argv) {
     g.pre = mode >= 1 ? pre : nullptr; g.add = mode >= 2 ? add : nullptr; g.flags = mode >= 1 ? (F_SILU_OUT | F_SAVE_PRE) : 0;
     const dim3 grid((unsigned)((ld / bt::BN) * ((M + bt::BM - 1) / bt::BM)));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((bt::k_bt_gemm_x6<false, 2>), grid, dim3(256), 0, 0, g);
+    auto launch = [&]() { hipLaunchKernelGGL((bt::k_bt_gemm_x6<false, 2>), grid, dim3(256), 0, 0, g); };
+    for (int i = 0; i < 3; ++i) launch();
     hipEventRecord(e0);
-    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((bt::k_bt_gemm_x6<false, 2>), grid, dim3(256), 0, 0, g);
+    for (int i = 0; i < 10; ++i) launch();
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double us = ms * 100.0;
