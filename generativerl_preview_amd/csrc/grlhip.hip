@@ -122,8 +122,10 @@ int grlhip_plan_program_info(const grlhip_plan* plan, int program, int32_t* n_op
   const Plan* p = plan->p;
   const std::vector<Op>& prog = program == 0 ? p->fwd : program == 1 ? p->grad : program == 2 ? p->train_fwd : p->train_bwd;
   int launches = 0;
-  for (size_t i = 0; i < prog.size(); ++i, ++launches)
+  for (size_t i = 0; i < prog.size(); ++i, ++launches) {
     if (batch_fusable(p, prog, i)) ++i;
+    else if (prog[i].type == OP_DW) ++launches;   // partial tiles + the ordered reduce
+  }
   if (n_ops) *n_ops = (int32_t)prog.size();
   if (n_launches) *n_launches = launches;
   return 0;
@@ -154,17 +156,26 @@ int grlhip_pack_weights(const grlhip_plan* plan, const void* const* params, int 
   if (dtype == GRLHIP_BF16 && bf16_fused_ok(p)) return bf16_pack(p, params, packed, st, g_err);
   if (dtype != GRLHIP_F32 && dtype != GRLHIP_BF16) return fail(GRLHIP_ERR_UNSUPPORTED, "unknown dtype");
   float* dst = (float*)packed;
+  PackBatch pb{};
+  auto flush = [&]() {
+    if (pb.n) hipLaunchKernelGGL(k_pack_f32_many, dim3((unsigned)pb.first_block[pb.n]), dim3(256), 0, st, pb);
+    pb.n = 0;
+  };
   for (const LinearDesc& l : p->linears) {
-    PackArgs a{};
+    PackArgs& a = pb.a[pb.n];
+    a = PackArgs{};
     a.src_w = (const float*)params[l.p_w];
     a.src_b = l.p_b >= 0 ? (const float*)params[l.p_b] : nullptr;
     a.dst = dst; a.N = l.N; a.K = l.K; a.Npad = l.Npad; a.Kpad = l.Kpad;
     a.col0 = l.col0; a.src_cols = l.src_cols; a.transposed = l.transposed;
     a.w_off = l.w_off; a.b_off = l.b_off;
     const int64_t total = (int64_t)l.Npad * l.Kpad + l.Npad;
-    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 1024);
-    hipLaunchKernelGGL(k_pack_f32, dim3(blocks), dim3(256), 0, st, a);
+    const int blocks = (int)std::min<int64_t>((total + 1023) / 1024, 256);
+    if (pb.n == 0) pb.first_block[0] = 0;
+    pb.first_block[pb.n + 1] = pb.first_block[pb.n] + blocks;
+    if (++pb.n == PACK_BATCH) flush();
   }
+  flush();
   const int half = p->desc.t_dim / 2;
   if (half)
     hipLaunchKernelGGL(k_copy_pad_f32, dim3(1), dim3(64), 0, st, (const float*)params[0], dst + p->fourier_off, half,

@@ -59,6 +59,13 @@ def main():
         return loss if gl_loss is None else gl_loss
 
     elapsed, loss = ranks.timed(step, args.warmup, args.steps)
+    import ctypes
+    from generativerl_preview_amd import _lib as L
+    launches = 0
+    for prog in (2, 3):   # training forward / backward programs of the policy net
+        n_ops, n_l = ctypes.c_int32(), ctypes.c_int32()
+        L.check(L.lib().grlhip_plan_program_info(m.model.plan.handle, prog, ctypes.byref(n_ops), ctypes.byref(n_l)))
+        launches += n_l.value
     assert bool(torch.isfinite(loss))
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -73,6 +80,10 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_TFLOPS, "traffic": None,
                          "note": "whole step per GPU over wall time; per-kernel split: scripts/profile_train.sh"},
+            "library_launches_per_step": launches + 4 + 4,
+            "launch_note": "op programs %d (GEMM / dW + ordered reduce / elementwise) + inputs, loss, Fourier gradient (2) + "
+                           "repack of the 49 packed linears after Adam (3 batched launches + the Fourier row); torch adds the "
+                           "loss prep, Adam (multi-tensor) and the flat-buffer zero" % launches,
             "final_loss": float(loss.detach())}), flush=True)
     ranks.close()
 
