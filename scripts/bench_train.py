@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 FLOP_PER_ROW = 9759936        # fwd + bwd = 3 x 2 x 1 626 656 MAC, SURVEY.md section 8d
-PEAK_F32_TFLOPS = 157.3       # MI355X dense fp32 MFMA
+PEAK_F32_TFLOPS = 2500.0 / 6   # fp32 products = six bf16 MFMAs each: dense bf16 peak / 6; fp32-MFMA peak: 157.3
 BATCH = 65536
 
 
@@ -78,7 +78,7 @@ def main():
             "config": {"workload": "C3 GMPO ICFM training step, batch %d per GPU, net [512,256,128], obs 17 / act 6, sigma 0.1" % B,
                        "parallelism": "data parallel x%d, one flat fp32 all-reduce per step" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F32_TFLOPS, "frac_of_fp32_mfma_peak_157.3": achieved / 157.3, "traffic": None,
                          "note": "whole step per GPU over wall time; per-kernel split: scripts/profile_train.sh"},
             "library_launches_per_step": launches + 4 + 4,
             "launch_note": "op programs %d (GEMM / dW + ordered reduce / elementwise) + inputs, loss, Fourier gradient (2) + "
