@@ -6,11 +6,6 @@ import torch
 from . import _lib as L
 
 
-# when set to a list, NetPlan.sample appends (start_event, end_event) pairs recorded on the launch
-# stream right around the fused-integrator launch (bench.py's roofline measurement)
-KERNEL_EVENTS = None
-
-
 def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -208,10 +203,6 @@ class NetPlan:
         ws = self.workspace(rows, dev, guidance, dtype)
         g_h = guidance.handle if guidance is not None else None
         with torch.cuda.device(dev):
-            ev = None
-            if KERNEL_EVENTS is not None:
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                ev[0].record(torch.cuda.current_stream(dev))
             if dW is None:
                 L.check(L.lib().grlhip_sample_ode(self.handle, _ptr(packed), dtype, g_h, _ptr(guidance_packed),
                                                   _ptr(x0), _ptr(cond), _ptr(coef), n_steps, rows, _ptr(final),
@@ -220,9 +211,6 @@ class NetPlan:
                 L.check(L.lib().grlhip_sample_sde(self.handle, _ptr(packed), dtype, g_h, _ptr(guidance_packed),
                                                   _ptr(x0), _ptr(cond), _ptr(coef), _ptr(dW), n_steps, rows,
                                                   _ptr(final), _ptr(traj), _ptr(ws), ws.numel(), _stream(dev)))
-            if ev is not None:
-                ev[1].record(torch.cuda.current_stream(dev))
-                KERNEL_EVENTS.append(ev)
         return final, traj
 
 

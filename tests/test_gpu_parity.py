@@ -374,6 +374,32 @@ def test_bf16_fused_kernel_at_the_edges_of_its_shape_classes(x_dim, c_dim, guide
     close(exact, want, tol=TOL, what="fp32 class edge x%d c%s guided %d" % (x_dim, c_dim, guided), rel=True)
 
 
+def test_bf16_full_size_properties():
+    """BASELINE config C2 at its full per-GPU size (1 048 576 states x 32 candidates, 100 steps, + a ragged tail), where
+    the oracle is out of reach: size-independent properties.  (1) determinism: two launches agree bit for bit; (2) row
+    independence: any subset of rows run alone in a small launch gives bit-identical actions (a row's result must not
+    depend on its position, its tile mates or the workgroup that got it); (3) a handful of those rows against the oracle
+    at the absolute bf16 tolerance."""
+    kind, cfg, m, sd = _bf16_model("qgpo_noise")
+    rows = 1048576 * 32 + 37
+    gen = torch.Generator(device=DEV).manual_seed(77)
+    x0 = torch.randn(rows, 6, device=DEV, generator=gen)
+    cond = torch.randn(rows, 17, device=DEV, generator=gen)
+    t_span = torch.linspace(0.0, 1.0, 101)
+    a = m.sample(t_span=t_span, x_0=x0, condition=cond)
+    assert a.shape == (rows, 6) and bool(torch.isfinite(a).all())
+    b = m.sample(t_span=t_span, x_0=x0, condition=cond)
+    assert torch.equal(a, b), "two launches over the same inputs differ"
+    del b
+    pick = torch.cat([torch.randint(0, rows, (4000,), generator=torch.Generator().manual_seed(5)),
+                      torch.arange(rows - 70, rows), torch.arange(0, 26)]).to(DEV)
+    sub = m.sample(t_span=t_span, x_0=x0[pick].contiguous(), condition=cond[pick].contiguous())
+    assert torch.equal(sub, a[pick]), "rows computed alone differ from the same rows inside the full launch"
+    few = pick[-120:].cpu()
+    want = O.sample_forward_process(sd, cfg, kind, t_span, x_0=x0[few.to(DEV)].cpu(), condition=cond[few.to(DEV)].cpu())[-1]
+    close(a[few.to(DEV)].cpu(), want, tol=BF16_TOL, what="bf16 full-size launch, 120 rows vs oracle")
+
+
 def test_bf16_mixed_pair_is_rejected():
     """small net (batch engine, fp32-layout image) + the [256,256] energy net (fused-kernel fragment image): no
     bf16 kernel takes that pair; the library must say so instead of reading an image in the wrong layout."""
