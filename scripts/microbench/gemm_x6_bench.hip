@@ -22,20 +22,26 @@ int main(int argc, char** argv) {
   hipMemcpy(A, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   std::vector<float> hb((size_t)K * 4096); for (auto& v : hb) v = (rand() % 2001 - 1000) * 1e-3f;
   for (int64_t o = 0; o < K * ld; o += hb.size()) hipMemcpy(B + o, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
+  const int only_ns = argc > 2 ? atoi(argv[2]) : 0;   // 0: both
+  for (int ns = 2; ns <= 3; ++ns)
   for (int mode = 0; mode < 3; ++mode) {
+    if (only_ns && ns != only_ns) continue;
     bt::GemmArgs g{};
     g.A = A; g.bias = bias; g.B = B; g.C = C; g.M = M; g.K = K; g.lda = M; g.ld = ld;
     g.pre = mode >= 1 ? pre : nullptr; g.add = mode >= 2 ? add : nullptr; g.flags = mode >= 1 ? (F_SILU_OUT | F_SAVE_PRE) : 0;
     const dim3 grid((unsigned)((ld / bt::BN) * ((M + bt::BM - 1) / bt::BM)));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    auto launch = [&]() { hipLaunchKernelGGL((bt::k_bt_gemm_x6<false, 2>), grid, dim3(256), 0, 0, g); };
+    auto launch = [&]() {
+      if (ns == 2) hipLaunchKernelGGL((bt::k_bt_gemm_x6<false, 2, 2>), grid, dim3(256), 0, 0, g);
+      else hipLaunchKernelGGL((bt::k_bt_gemm_x6<false, 2, 3>), grid, dim3(256), 0, 0, g);
+    };
     for (int i = 0; i < 3; ++i) launch();
     hipEventRecord(e0);
     for (int i = 0; i < 10; ++i) launch();
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double us = ms * 100.0;
-    printf("ld %lld mode %d (%s): %.1f us  %.1f TFLOP/s fp32-equivalent  %.2f TB/s min traffic\n", (long long)ld, mode,
+    printf("stages %d ld %lld mode %d (%s): %.1f us  %.1f TFLOP/s fp32-equivalent  %.2f TB/s min traffic\n", ns, (long long)ld, mode,
            mode == 0 ? "plain" : mode == 1 ? "silu+pre" : "silu+pre+add", us, 2.0 * M * K * ld / us * 1e-6,
            ((double)(K + M * (1 + (mode >= 1) + (mode >= 2))) * ld * 4) / us * 1e-6);
   }
