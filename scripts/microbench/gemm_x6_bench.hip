@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <string>
 #include <cstdlib>
+#include <cmath>
 #include "plan.hpp"
 namespace grlhip { inline int device_cus() { return 256; } }
 #include "engine_batch.hip.inc"
@@ -23,7 +24,8 @@ int main(int argc, char** argv) {
   std::vector<float> hb((size_t)K * 4096); for (auto& v : hb) v = (rand() % 2001 - 1000) * 1e-3f;
   for (int64_t o = 0; o < K * ld; o += hb.size()) hipMemcpy(B + o, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
   const int only_ns = argc > 2 ? atoi(argv[2]) : 0;   // 0: both
-  for (int ns = 2; ns <= 3; ++ns)
+  hipFuncSetAttribute((const void*)bt::k_bt_gemm_x6p<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bt::gemm_p_lds_bytes<2>());
+  for (int ns = 2; ns <= 4; ++ns)   // 4: the pipelined kernel (16-k tiles, double-buffered LDS images)
   for (int mode = 0; mode < 3; ++mode) {
     if (only_ns && ns != only_ns) continue;
     bt::GemmArgs g{};
@@ -33,7 +35,8 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     auto launch = [&]() {
       if (ns == 2) hipLaunchKernelGGL((bt::k_bt_gemm_x6<false, 2, 2>), grid, dim3(256), 0, 0, g);
-      else hipLaunchKernelGGL((bt::k_bt_gemm_x6<false, 2, 3>), grid, dim3(256), 0, 0, g);
+      else if (ns == 3) hipLaunchKernelGGL((bt::k_bt_gemm_x6<false, 2, 3>), grid, dim3(256), 0, 0, g);
+      else hipLaunchKernelGGL((bt::k_bt_gemm_x6p<false, 2>), grid, dim3(256), bt::gemm_p_lds_bytes<2>(), 0, g);
     };
     for (int i = 0; i < 3; ++i) launch();
     hipEventRecord(e0);
@@ -44,6 +47,21 @@ int main(int argc, char** argv) {
     printf("stages %d ld %lld mode %d (%s): %.1f us  %.1f TFLOP/s fp32-equivalent  %.2f TB/s min traffic\n", ns, (long long)ld, mode,
            mode == 0 ? "plain" : mode == 1 ? "silu+pre" : "silu+pre+add", us, 2.0 * M * K * ld / us * 1e-6,
            ((double)(K + M * (1 + (mode >= 1) + (mode >= 2))) * ld * 4) / us * 1e-6);
+  }
+  {  // the pipelined kernel accumulates the same products in the same order: bit-identical outputs expected
+    bt::GemmArgs g{};
+    g.A = A; g.bias = bias; g.B = B; g.C = C; g.M = M; g.K = K; g.lda = M; g.ld = ld;
+    g.pre = pre; g.add = add; g.flags = F_SILU_OUT | F_SAVE_PRE;
+    const dim3 grid((unsigned)((ld / bt::BN) * ((M + bt::BM - 1) / bt::BM)));
+    std::vector<float> c0((size_t)M * 4096), c1((size_t)M * 4096);
+    hipLaunchKernelGGL((bt::k_bt_gemm_x6<false, 2, 2>), grid, dim3(256), 0, 0, g);
+    hipMemcpy(c0.data(), C, c0.size() * 4, hipMemcpyDeviceToHost);
+    hipMemset(C, 0, (size_t)M * ld * 4);
+    hipLaunchKernelGGL((bt::k_bt_gemm_x6p<false, 2>), grid, dim3(256), bt::gemm_p_lds_bytes<2>(), 0, g);
+    hipMemcpy(c1.data(), C, c1.size() * 4, hipMemcpyDeviceToHost);
+    size_t bad = 0; double mx = 0;
+    for (size_t i = 0; i < c0.size(); ++i) { if (c0[i] != c1[i]) ++bad; mx = std::max(mx, (double)fabsf(c0[i])); }
+    printf("pipelined vs two-barrier kernel: %zu of %zu outputs differ (max |C| %.3f)\n", bad, c0.size(), mx);
   }
   return 0;
 }
