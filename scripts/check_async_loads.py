@@ -109,7 +109,7 @@ def main():
             text = open(out).read()
     failed = False
     seen = 0
-    for m in re.finditer(r"^(_ZN6grlhip2bt(?:12k_bt_gemm_x6|13k_bt_gemm_x6p|10k_bt_dw_x6)\w+):[^\n]*\n", text, re.M):
+    for m in re.finditer(r"^(_ZN6grlhip2bt(?:12k_bt_gemm_x6|10k_bt_dw_x6)\w+):[^\n]*\n", text, re.M):
         name = m.group(1)
         end = text.index(".end_amdhsa_kernel", m.end())
         body = text[m.end():end]

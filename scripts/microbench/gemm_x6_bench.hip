@@ -12,6 +12,9 @@
 #include "plan.hpp"
 namespace grlhip { inline int device_cus() { return 256; } }
 #include "engine_batch.hip.inc"
+namespace grlhip { namespace bt {
+#include "gemm_x6_two_barrier.inc"
+} }
 using namespace grlhip;
 int main(int argc, char** argv) {
   const int M = 512, K = 512; const int64_t ld = argc > 1 ? atoll(argv[1]) : 65536;
@@ -24,7 +27,7 @@ int main(int argc, char** argv) {
   std::vector<float> hb((size_t)K * 4096); for (auto& v : hb) v = (rand() % 2001 - 1000) * 1e-3f;
   for (int64_t o = 0; o < K * ld; o += hb.size()) hipMemcpy(B + o, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
   const int only_ns = argc > 2 ? atoi(argv[2]) : 0;   // 0: both
-  hipFuncSetAttribute((const void*)bt::k_bt_gemm_x6p<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bt::gemm_p_lds_bytes<2>());
+  hipFuncSetAttribute((const void*)bt::k_bt_gemm_x6<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bt::gemm_lds_bytes<2>());
   for (int ns = 2; ns <= 4; ++ns)   // 4: the pipelined kernel (16-k tiles, double-buffered LDS images)
   for (int mode = 0; mode < 3; ++mode) {
     if (only_ns && ns != only_ns) continue;
@@ -34,9 +37,9 @@ int main(int argc, char** argv) {
     const dim3 grid((unsigned)((ld / bt::BN) * ((M + bt::BM - 1) / bt::BM)));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     auto launch = [&]() {
-      if (ns == 2) hipLaunchKernelGGL((bt::k_bt_gemm_x6<false, 2, 2>), grid, dim3(256), 0, 0, g);
-      else if (ns == 3) hipLaunchKernelGGL((bt::k_bt_gemm_x6<false, 2, 3>), grid, dim3(256), 0, 0, g);
-      else hipLaunchKernelGGL((bt::k_bt_gemm_x6p<false, 2>), grid, dim3(256), bt::gemm_p_lds_bytes<2>(), 0, g);
+      if (ns == 2) hipLaunchKernelGGL((bt::k_bt_gemm_x6_two_barrier<false, 2, 2>), grid, dim3(256), 0, 0, g);
+      else if (ns == 3) hipLaunchKernelGGL((bt::k_bt_gemm_x6_two_barrier<false, 2, 3>), grid, dim3(256), 0, 0, g);
+      else hipLaunchKernelGGL((bt::k_bt_gemm_x6<false, 2>), grid, dim3(256), bt::gemm_lds_bytes<2>(), 0, g);
     };
     for (int i = 0; i < 3; ++i) launch();
     hipEventRecord(e0);
@@ -54,10 +57,10 @@ int main(int argc, char** argv) {
     g.pre = pre; g.add = add; g.flags = F_SILU_OUT | F_SAVE_PRE;
     const dim3 grid((unsigned)((ld / bt::BN) * ((M + bt::BM - 1) / bt::BM)));
     std::vector<float> c0((size_t)M * 4096), c1((size_t)M * 4096);
-    hipLaunchKernelGGL((bt::k_bt_gemm_x6<false, 2, 2>), grid, dim3(256), 0, 0, g);
+    hipLaunchKernelGGL((bt::k_bt_gemm_x6_two_barrier<false, 2, 2>), grid, dim3(256), 0, 0, g);
     hipMemcpy(c0.data(), C, c0.size() * 4, hipMemcpyDeviceToHost);
     hipMemset(C, 0, (size_t)M * ld * 4);
-    hipLaunchKernelGGL((bt::k_bt_gemm_x6p<false, 2>), grid, dim3(256), bt::gemm_p_lds_bytes<2>(), 0, g);
+    hipLaunchKernelGGL((bt::k_bt_gemm_x6<false, 2>), grid, dim3(256), bt::gemm_lds_bytes<2>(), 0, g);
     hipMemcpy(c1.data(), C, c1.size() * 4, hipMemcpyDeviceToHost);
     size_t bad = 0; double mx = 0;
     for (size_t i = 0; i < c0.size(); ++i) { if (c0[i] != c1[i]) ++bad; mx = std::max(mx, (double)fabsf(c0[i])); }
