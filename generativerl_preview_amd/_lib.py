@@ -50,6 +50,8 @@ PROTOTYPES = {
     "grlhip_energy_grad": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _f, _vp, _i64, _vp, _sz, _vp]),
     "grlhip_sample_ode": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp,
                                          _vp, _sz, _vp]),
+    "grlhip_sample_fixed": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp,
+                                           _vp, _vp, _vp, _vp, _sz, _vp]),
     "grlhip_static_scratch_bytes": (_sz, []),
     "grlhip_sample_ode_static": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp]),
     "grlhip_sample_sde": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp,

@@ -283,6 +283,40 @@ int grlhip_sample_ode(const grlhip_plan* plan, const void* packed, int dtype, co
                        out_final, out_traj, workspace, workspace_bytes, stream);
 }
 
+int grlhip_sample_fixed(const grlhip_plan* plan, const void* packed, int dtype, const grlhip_plan* guidance,
+                        const void* guidance_packed, const float* x0, const float* cond, const float* coef,
+                        const float* dW, int32_t n_steps, int64_t rows, const float* fixed_x, const float* fixed_mask,
+                        const float* fix_sc, const float* fix_noise, float* out_final, float* out_traj,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_ready(plan, packed)) return rc;
+  const Plan* p = plan->p;
+  if (p->desc.kind != GRLHIP_NET_RESNET) return fail(GRLHIP_ERR_INVALID, "sampling needs a RESNET plan");
+  if (p->desc.out_dim != p->desc.x_dim) return fail(GRLHIP_ERR_INVALID, "sampling needs out_dim == x_dim");
+  if (rows <= 0) return 0;
+  if (n_steps < 0) return fail(GRLHIP_ERR_INVALID, "n_steps < 0");
+  if (!x0 || !out_final || (n_steps > 0 && (!coef || !fix_sc))) return fail(GRLHIP_ERR_INVALID, "null x0/out_final/coef/fix_sc");
+  if (!fixed_x || !fixed_mask) return fail(GRLHIP_ERR_INVALID, "null fixed_x / fixed_mask");
+  if ((p->desc.cond_dim > 0) != (cond != nullptr))
+    return fail(GRLHIP_ERR_INVALID, "condition pointer does not match the plan's cond_dim");
+  const Plan* g = nullptr;
+  if (guidance) {
+    if (int rc = check_ready(guidance, guidance_packed)) return rc;
+    g = guidance->p;
+    if (g->desc.kind != GRLHIP_NET_CONCAT_MLP || g->desc.x_dim != p->desc.x_dim || g->desc.cond_dim != p->desc.cond_dim)
+      return fail(GRLHIP_ERR_INVALID, "guidance plan must be a CONCAT_MLP over the same x/cond dims");
+  }
+  if (dtype != GRLHIP_F32 && dtype != GRLHIP_BF16) return fail(GRLHIP_ERR_UNSUPPORTED, "unknown dtype");
+  if (dtype == GRLHIP_BF16 && (bf16_fused_ok(p) || (g && bf16_fused_ok(g))))
+    return fail(GRLHIP_ERR_UNSUPPORTED, "sample_fixed runs on the batch engine: the fused bf16 integrator has no fixed-component form; use GRLHIP_F32 images for this network");
+  const size_t need = grlhip_workspace_bytes(plan, guidance, rows, dtype);
+  if (!workspace || workspace_bytes < need) return fail(GRLHIP_ERR_WORKSPACE, "workspace too small: need " + std::to_string(need));
+  SampleCall c{x0, cond, coef, dW, out_final, out_traj, rows, n_steps};
+  c.fixed = fixed_x; c.mask = fixed_mask; c.fix_sc = fix_sc; c.fix_noise = fix_noise;
+  batch_sample(p, (const float*)packed, g, (const float*)guidance_packed, c, (float*)workspace, (hipStream_t)stream, dtype == GRLHIP_BF16, false);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 int grlhip_bf16_fused_kernel(const grlhip_plan* plan, const grlhip_plan* guidance, char* name_buf, size_t name_buf_len) {
   if (!plan || !plan->p) return fail(GRLHIP_ERR_INVALID, "null plan");
   const Plan* g = guidance ? guidance->p : nullptr;

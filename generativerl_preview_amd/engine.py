@@ -214,6 +214,33 @@ class NetPlan:
         return final, traj
 
 
+    def sample_fixed(self, packed, x0, cond, coef, fixed_x, fixed_mask, fix_sc, fix_noise=None, dW=None, guidance=None,
+                     guidance_packed=None, trajectory_slots=0, dtype=L.F32):
+        """Sampling with pinned components (include/grlhip.h, grlhip_sample_fixed).  fixed_x / fixed_mask: (rows, D);
+        fix_sc: (n_steps, 2) = scale / std of the forward path at each step's network time; fix_noise:
+        (n_steps, rows, D) or None.  Returns (final, traj|None); traj slot 0 is the blended initial state."""
+        rows, D = x0.shape
+        dev = x0.device
+        x0, cond = _f32c(x0, "x_0", (rows, self.x_dim)), _f32c(cond, "condition")
+        coef = _f32c(coef.to(dev), "coef")
+        n_steps = coef.shape[0]
+        assert coef.dim() == 2 and coef.shape[1] == L.COEF_STRIDE
+        fixed_x, fixed_mask = _f32c(fixed_x, "fixed_x", (rows, D)), _f32c(fixed_mask, "fixed_mask", (rows, D))
+        fix_sc = _f32c(fix_sc.to(dev), "fix_sc", (n_steps, 2))
+        fix_noise = _f32c(fix_noise, "fixed noise", (n_steps, rows, D)) if fix_noise is not None else None
+        dW = _f32c(dW, "noise increments", (n_steps, rows, D)) if dW is not None else None
+        final = torch.empty(rows, D, dtype=torch.float32, device=dev)
+        traj = torch.empty(trajectory_slots, rows, D, dtype=torch.float32, device=dev) if trajectory_slots else None
+        ws = self.workspace(rows, dev, guidance, dtype)
+        g_h = guidance.handle if guidance is not None else None
+        with torch.cuda.device(dev):
+            L.check(L.lib().grlhip_sample_fixed(self.handle, _ptr(packed), dtype, g_h, _ptr(guidance_packed), _ptr(x0),
+                                                _ptr(cond), _ptr(coef), _ptr(dW), n_steps, rows, _ptr(fixed_x),
+                                                _ptr(fixed_mask), _ptr(fix_sc), _ptr(fix_noise), _ptr(final), _ptr(traj),
+                                                _ptr(ws), ws.numel(), _stream(dev)))
+        return final, traj
+
+
 class _DifferentiableForward(torch.autograd.Function):
     """net(t, x, cond) with a backward to the parameters and to x (grlhip_net_backward); no gradient to t / cond."""
 

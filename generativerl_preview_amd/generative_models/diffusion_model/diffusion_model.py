@@ -118,6 +118,87 @@ class DiffusionModel(nn.Module):
         data = reshape_output(self, data, batch_size, extra, n, x_0, condition)
         return data[-1] if _final_only else data
 
+    # ------------------------------------------------------------------ sampling with pinned components
+    def sample_with_fixed_x(self, fixed_x, fixed_mask, t_span: torch.Tensor = None, batch_size=None, x_0=None,
+                            condition=None, with_grad: bool = False, solver_config=None, **kw):
+        """diffusion_model.py:472-519 -- final state of ``sample_forward_process_with_fixed_x``."""
+        return self.sample_forward_process_with_fixed_x(fixed_x=fixed_x, fixed_mask=fixed_mask, t_span=t_span,
+                                                        batch_size=batch_size, x_0=x_0, condition=condition,
+                                                        with_grad=with_grad, solver_config=solver_config,
+                                                        _final_only=True, **kw)
+
+    def sample_forward_process_with_fixed_x(self, fixed_x, fixed_mask, t_span: torch.Tensor = None, batch_size=None,
+                                            x_0=None, condition=None, with_grad: bool = False, solver_config=None,
+                                            fixed_noise=None, noise_increments=None, _final_only=False,
+                                            _guidance_scale=None):
+        """diffusion_model.py:521-859: sampling with some components pinned to ``fixed_x`` (``fixed_mask`` is 1 where
+        a component is generated, 0 where it is pinned).  The whole Euler / Euler-Maruyama loop is one library call
+        (grlhip_sample_fixed, fp32 batch engine).  Returns (T, N, D), or (T, *B, N, D) with ``batch_size``.
+        ``fixed_noise`` (superset, (n_steps, B*N, D)) pins the Gaussian draws that the reference makes inside the drift
+        (``direct_sample``, one per solver step); ``noise_increments`` pins the Brownian path of the SDE solver."""
+        if t_span is not None:
+            t_span = t_span.to(self.device)
+        if batch_size is None:
+            extra = (1,)
+        elif isinstance(batch_size, int):
+            extra = (batch_size,)
+        elif isinstance(batch_size, (torch.Size, Tuple, List)):
+            extra = tuple(int(b) for b in batch_size)
+        else:
+            assert False, "Invalid batch size"
+        n = fixed_x.shape[0]
+        assert fixed_x.shape[0] == fixed_mask.shape[0], "The batch size of fixed_x and fixed_mask must be the same"
+        if x_0 is not None and condition is not None:
+            assert x_0.shape[0] == condition.shape[0], "The batch size of x_0 and condition must be the same"
+        if x_0 is not None:
+            assert x_0.shape[0] == n, "The batch size of x_0 and fixed_x must be the same"
+        elif condition is not None:
+            assert condition.shape[0] == n, "The batch size of condition and fixed_x must be the same"
+        if solver_config is not None:
+            solver_config = as_config(solver_config)
+            solver = get_solver(solver_config.type)(**solver_config.args)
+        else:
+            assert hasattr(self, "solver"), "solver must be specified in config or solver_config"
+            solver = self.solver
+        rep = 1
+        for b in extra:
+            rep *= b
+        if x_0 is None:
+            x = self.gaussian_generator(batch_size=rep * n)
+        else:
+            xs = torch.Size([self.x_size]) if isinstance(self.x_size, int) else torch.Size(self.x_size)
+            assert xs == x_0[0].shape, "The shape of x_0 must be the same as the x_size that is specified in the config"
+            x = torch.repeat_interleave(x_0, rep, dim=0)
+        if condition is not None:
+            condition = torch.repeat_interleave(condition, rep, dim=0)
+        fixed_x = torch.repeat_interleave(fixed_x.to(self.device, torch.float32), rep, dim=0)
+        fixed_mask = torch.repeat_interleave(fixed_mask.to(self.device, torch.float32), rep, dim=0)
+        function, function_type = self._function(_guidance_scale)
+        if isinstance(solver, DPMSolver):
+            assert False, "Not implemented"   # diffusion_model.py:641-643
+        elif isinstance(solver, ODESolver):
+            drift = self.diffusion_process.reverse_ode(function=function, function_type=function_type,
+                                                       condition=condition).drift.with_fixed(fixed_x, fixed_mask, fixed_noise)
+            data = solver.integrate(drift=drift, x0=x, t_span=t_span, return_trajectory=not _final_only, with_grad=with_grad)
+        elif isinstance(solver, SDESolver):
+            assert self.reverse_diffusion_process is not None, "reverse_path must be specified in config"
+            sde = self.diffusion_process.reverse_sde(
+                function=function, function_type=function_type, condition=condition,
+                reverse_diffusion_function=self.reverse_diffusion_process.diffusion,
+                reverse_diffusion_squared_function=self.reverse_diffusion_process.diffusion_squared)
+            d = sde.drift.with_fixed(fixed_x, fixed_mask, fixed_noise)
+            data = solver.integrate(drift=d, diffusion=d, x0=x, t_span=t_span, noise_increments=noise_increments,
+                                    return_trajectory=not _final_only, with_grad=with_grad)
+        else:
+            raise NotImplementedError("Solver type {} is not implemented".format(type(solver).__name__))
+        if _final_only:
+            data = data.unsqueeze(0)
+        xs = (self.x_size,) if isinstance(self.x_size, int) else tuple(self.x_size)
+        data = data.reshape(data.shape[0], *extra, n, *xs)
+        if batch_size is None:
+            data = data.squeeze(1)
+        return data[-1] if _final_only else data
+
     # ------------------------------------------------------------------ training
     def score_matching_loss(self, x, condition=None, weighting_scheme: str = None, average: bool = True,
                             t=None, noise=None):

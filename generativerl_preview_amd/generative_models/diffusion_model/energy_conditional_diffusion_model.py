@@ -83,6 +83,28 @@ class EnergyConditionalDiffusionModel(DiffusionModel):
                                               with_grad=with_grad, solver_config=solver_config,
                                               _guidance_scale=guidance_scale, **kw)
 
+    def sample_with_fixed_x(self, fixed_x, fixed_mask, t_span=None, batch_size=None, x_0=None, condition=None,
+                            guidance_scale: float = 1.0, with_grad: bool = False, solver_config=None, **kw):
+        """:617-667"""
+        return super().sample_forward_process_with_fixed_x(
+            fixed_x=fixed_x, fixed_mask=fixed_mask, t_span=t_span, batch_size=batch_size, x_0=x_0, condition=condition,
+            with_grad=with_grad, solver_config=solver_config, _final_only=True, _guidance_scale=guidance_scale, **kw)
+
+    def sample_forward_process_with_fixed_x(self, fixed_x, fixed_mask, t_span=None, batch_size=None, x_0=None,
+                                            condition=None, guidance_scale: float = 1.0, with_grad: bool = False,
+                                            solver_config=None, **kw):
+        """:669-1036 -- the guided score integrated with pinned components"""
+        return super().sample_forward_process_with_fixed_x(
+            fixed_x=fixed_x, fixed_mask=fixed_mask, t_span=t_span, batch_size=batch_size, x_0=x_0, condition=condition,
+            with_grad=with_grad, solver_config=solver_config, _guidance_scale=guidance_scale, **kw)
+
+    def sample_with_fixed_x_without_energy_guidance(self, fixed_x, fixed_mask, t_span=None, batch_size=None, x_0=None,
+                                                    condition=None, with_grad: bool = False, solver_config=None):
+        """:1038-1083"""
+        return self.sample_with_fixed_x(fixed_x=fixed_x, fixed_mask=fixed_mask, t_span=t_span, batch_size=batch_size,
+                                        x_0=x_0, condition=condition, guidance_scale=0.0, with_grad=with_grad,
+                                        solver_config=solver_config)
+
     def sample_without_energy_guidance(self, t_span=None, batch_size=None, x_0=None, condition=None,
                                        with_grad: bool = False, solver_config=None):
         """:215-255"""

@@ -37,6 +37,17 @@ class FusedDrift:
         self.kind, self.model, self.model_type = kind, model, model_type
         self.path, self.reverse_path, self.condition = path, reverse_path, condition
         self.guidance, self.guidance_scale, self.T = guidance, float(guidance_scale), T
+        self.fixed = None   # (fixed_x, fixed_mask, noise | None): see with_fixed
+
+    def with_fixed(self, fixed_x, fixed_mask, noise=None):
+        """The same drift with some components pinned (diffusion_model.py:647-661): evaluated at
+        ``direct_sample(T - t, fixed_x) * (1 - mask) + x * mask`` and multiplied by the mask.  ``noise``
+        (n_steps, R, D) are the Gaussian draws of ``direct_sample``, one per solver step (drawn with ``torch.randn``
+        on the device when None)."""
+        import copy
+        d = copy.copy(self)
+        d.fixed = (fixed_x, fixed_mask, noise)
+        return d
 
     # ---- per-step coefficients at solver times t (1-D fp32 CPU tensor) -> tau, a, b, g, s
     def coefficients(self, t):
@@ -98,8 +109,23 @@ class FusedDrift:
         m = self.model
         dtype = m.compute_dtype if dtype is None else dtype
         g_plan = g_packed = None
+        if self.fixed is not None:
+            dtype = L.F32   # the batch engine (the fused bf16 integrator has no fixed-component form)
         if self.guidance is not None:
             g_plan, g_packed = self.guidance.plan, self.guidance.packed(L.F32 if dtype == L.F32 else dtype)
+        if self.fixed is not None:
+            if self.kind == "icfm":
+                raise NotImplementedError("fixed-component sampling is defined for diffusion paths only")
+            fx, mask, noise = self.fixed
+            tau = table[:, 0].to("cpu", torch.float32)
+            fix_sc = torch.stack([self.path.scale(tau), self.path.std(tau)], 1).to(torch.float32).contiguous()
+            rows = x0.shape[0]
+            flat = lambda v: v.reshape(rows, -1)   # noqa: E731
+            if noise is None:
+                noise = torch.randn(table.shape[0], rows, flat(x0).shape[1], device=x0.device, dtype=torch.float32)
+            return m.plan.sample_fixed(m.packed(dtype), flat(x0), self.condition, table, flat(fx), flat(mask), fix_sc,
+                                       fix_noise=noise.reshape(table.shape[0], rows, -1), dW=increments, guidance=g_plan,
+                                       guidance_packed=g_packed, trajectory_slots=trajectory_slots, dtype=dtype)
         return m.plan.sample(m.packed(dtype), x0, self.condition, table, dW=increments, guidance=g_plan,
                              guidance_packed=g_packed, trajectory_slots=trajectory_slots, dtype=dtype)
 
@@ -110,6 +136,8 @@ class FusedDrift:
         Energy-guided chains: the reference detaches the guidance term (``calculate_energy_guidance`` returns
         ``guidance.detach()``, energy_conditional_diffusion_model.py:87-92), so it enters the forward chain only; the
         backward is the unguided chain rule along the guided trajectory, with no gradient to the energy net."""
+        if self.fixed is not None:
+            raise NotImplementedError("with_grad=True is not implemented for sampling with fixed components")
         named = self.model._named()
         params = [named[n] for n, _ in self.model.plan.params]
         return _DifferentiableOde.apply(self, table, increments, x0, *params)

@@ -155,6 +155,27 @@ int grlhip_sample_ode(const grlhip_plan* plan, const void* packed, int dtype,
                       int64_t rows, float* out_final, float* out_traj,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* Replaces: the Euler / Euler-Maruyama loop of DiffusionModel.sample_forward_process_with_fixed_x
+ * (grl/generative_models/diffusion_model/diffusion_model.py:521-772; energy-guided:
+ * diffusion_model/energy_conditional_diffusion_model.py:669-960) -- sampling with some components pinned
+ * ("inpainting"): fixed_mask[R,D] is 1 where a component is generated and 0 where it is pinned to fixed_x[R,D]
+ * (any value in between blends, as the reference's arithmetic does).
+ *   state_0 = fixed_x*(1 - mask) + x0*mask
+ *   xin_k   = (s_k*fixed_x + sigma_k*noise_k)*(1 - mask) + state_k*mask      (diffusion_process.direct_sample, :939-956)
+ *   state_{k+1} = state_k + mask * (dt*(a*xin_k + b*net(tau, xin_k, c) + g*dE/dx(tau, xin_k, c)) + s*dW_k)
+ * with the coef table of grlhip_sample_ode / _sde, fix_sc[n_steps][2] = {s_k, sigma_k} (scale and std of the forward
+ * path at the step's network time) and fix_noise[n_steps][R][D] the Gaussian draws of direct_sample (NULL = zeros; the
+ * reference draws them inside the drift, so passing them is what makes a run reproducible).  dW may be NULL (ODE).
+ * Runs on the batch engine (GRLHIP_F32, or GRLHIP_BF16 for networks without a fused integrator; a network whose
+ * GRLHIP_BF16 image is the fused integrator's: GRLHIP_ERR_UNSUPPORTED).  Workspace: grlhip_workspace_bytes.
+ * out_final[R,D] = state after the last step; out_traj as in grlhip_sample_ode (slot 0 = state_0). */
+int grlhip_sample_fixed(const grlhip_plan* plan, const void* packed, int dtype,
+                        const grlhip_plan* guidance, const void* guidance_packed,
+                        const float* x0, const float* cond, const float* coef, const float* dW, int32_t n_steps,
+                        int64_t rows, const float* fixed_x, const float* fixed_mask, const float* fix_sc,
+                        const float* fix_noise, float* out_final, float* out_traj,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* No counterpart in the reference.  For callers that cannot allocate device memory or hand over a workspace --
  * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc: grlhip_sample_ode on the fused
  * bf16 integrator (GRLHIP_BF16 images of networks that have one; anything else: GRLHIP_ERR_UNSUPPORTED) with the

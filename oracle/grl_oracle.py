@@ -369,6 +369,51 @@ def sample_forward_process(sd, cfg, kind, t_span, batch_size=None, x_0=None, con
     return _reshape_out(data, batch_size, extra, n, cfg["x_size"], x_0, condition)
 
 
+def sample_forward_process_with_fixed_x(sd, cfg, kind, t_span, fixed_x, fixed_mask, fixed_noise, batch_size=None,
+                                        x_0=None, condition=None, x_T=None, guidance_scale=1.0, solver="ODESolver",
+                                        dt=None, increments=None):
+    """DiffusionModel / EnergyConditionalDiffusionModel ``sample_forward_process_with_fixed_x``
+    (diffusion_model.py:521-859, energy_conditional_diffusion_model.py:669-1036): the drift (and the diffusion) are
+    evaluated at ``direct_sample(t_max - t, fixed_x) * (1 - mask) + x * mask`` and multiplied by the mask
+    (diffusion_model.py:647-661,725-752).  ``direct_sample`` (diffusion_process.py:939-956) draws fresh Gaussian noise
+    at every call; ``fixed_noise[k]`` (n_steps, prod(B)*N, D) is the draw of the k-th DRIFT evaluation (the SDE
+    branch's diffusion closure draws too, but g does not depend on x, so that draw only advances the generator)."""
+    extra, _ = _expand_batch(batch_size, x_0, condition)
+    n = fixed_x.shape[0]
+    rep = int(math.prod(extra))
+    x = x_T if x_0 is None else torch.repeat_interleave(x_0, rep, dim=0)
+    cond = None if condition is None else torch.repeat_interleave(condition, rep, dim=0)
+    fx = torch.repeat_interleave(fixed_x, rep, dim=0)
+    m = torch.repeat_interleave(fixed_mask, rep, dim=0)
+    mt = cfg["model"]["type"]
+    path = Path(cfg["path"])
+    if kind == "energy":
+        fn = lambda t, y: guided_score(sd, mt, path, t, y, cond, guidance_scale)  # noqa: E731
+        ftype = "score_function"
+    else:
+        fn = lambda t, y: intrinsic_forward(sd, t, y, cond)  # noqa: E731
+        ftype = mt
+    x = fx * (1 - m) + x * m
+    calls = [0]
+
+    def partially_fixed(t, y):
+        tau = 1.0 - t
+        eps = fixed_noise[calls[0]]
+        calls[0] += 1
+        return (_b(path.scale(tau), fx) * fx + _b(path.std(tau), fx) * eps) * (1 - m) + y * m
+
+    if solver == "ODESolver":
+        data = euler_ode(lambda t, y: m * reverse_ode_drift(ftype, path, fn, t, partially_fixed(t, y)), x, t_span)
+    else:
+        rpath = Path(cfg["reverse_path"])
+        data = euler_maruyama(lambda t, y: m * reverse_sde_drift(ftype, path, rpath, fn, t, partially_fixed(t, y)),
+                              lambda t, y: m * reverse_sde_diffusion(rpath, t, y),
+                              x, t_span, dt, increments)
+    xs = (cfg["x_size"],) if isinstance(cfg["x_size"], int) else tuple(cfg["x_size"])
+    data = data.reshape(-1, *extra, n, *xs)
+    return data.squeeze(1) if batch_size is None else data
+
+
 # ----------------------------------------------------------------------------- losses
 def _row_loss(pred, target, average):
     per_row = torch.sum(0.5 * (pred - target) ** 2, dim=1)

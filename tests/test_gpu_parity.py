@@ -628,3 +628,95 @@ def test_sde_dt_not_matching_the_grid_vs_oracle(dt, Tn):
     want = O.sample_forward_process(sd, cfg, kind, t_span, batch_size=rows, x_T=xT, solver="SDESolver", dt=dt,
                                     increments=dW)
     close(got, want, tol=2e-4, what="sde dt=%g" % dt)
+
+
+FIXED_X_MODELS = ("small_vp_noise", "small_vp_score", "small_gvp_velocity", "small_uncond_noise", "small_energy", "qgpo_noise")
+
+
+@pytest.mark.parametrize("name", FIXED_X_MODELS)
+def test_sampling_with_fixed_x_vs_golden(name):
+    """sample_forward_process_with_fixed_x / sample_with_fixed_x (grlhip_sample_fixed) against the reference's own
+    trajectories (tests/golden/make_golden_fixed_x.py): pinned, free and fractionally masked components, x_0 given or
+    drawn, extra batch sizes, guided and unguided, ODE and Euler-Maruyama."""
+    kind, cfg, m = um.build(name, DEV)
+    g = gu.load("fixed_x.npz")
+    pre = name + "/"
+    x0, fx, mask = cu(g[pre + "x0"]), cu(g[pre + "fixed_x"]), cu(g[pre + "mask"])
+    cond = cu(g[pre + "cond"]) if pre + "cond" in g else None
+    t_span = torch.linspace(0.0, 1.0, 7)
+    rel = name in REL_TRAJ
+    n = 0
+    for tag, B, use_x0 in (("x0", None, True), ("B2_x0", 2, True), ("B3_draw", 3, False)):
+        for gs in ((0.0, 1.0) if kind == "energy" else (None,)):
+            key = "%sode_%s%s" % (pre, tag, "" if gs is None else "_g%g" % gs)
+            kw = dict(fixed_x=fx, fixed_mask=mask, t_span=t_span, batch_size=B, x_0=x0 if use_x0 else None,
+                      condition=cond, fixed_noise=cu(g["%sode_%s_noise" % (pre, tag)]))
+            if gs is not None:
+                kw["guidance_scale"] = gs
+            if not use_x0:
+                um.fix_noise(m, cu(g["%sode_%s_xT" % (pre, tag)]))
+            traj = m.sample_forward_process_with_fixed_x(**kw)
+            close(traj, g[key], what=key, rel=rel)
+            final = m.sample_with_fixed_x(**kw)
+            close(final, g[key][-1], what=key + " final", rel=rel)
+            n += 1
+    for gs in ((0.0, 1.0) if kind == "energy" else (None,)):
+        key = "%ssde%s" % (pre, "" if gs is None else "_g%g" % gs)
+        if key not in g:
+            continue
+        kw = dict(fixed_x=fx, fixed_mask=mask, t_span=torch.linspace(0.0, 1.0, 5), x_0=x0, condition=cond,
+                  fixed_noise=cu(g[pre + "sde_noise"]), noise_increments=cu(g[pre + "sde_dW"]),
+                  solver_config=dict(type="SDESolver", args=dict(library="torchsde", dt=0.25)))
+        if gs is not None:
+            kw["guidance_scale"] = gs
+        close(m.sample_forward_process_with_fixed_x(**kw), g[key], what=key)
+        n += 1
+    assert n >= 3
+
+
+def test_sampling_with_fixed_x_shapes_and_invariants():
+    """The calls of the reference's own unit test (grl/unittest/generative_models/diffusion_model/
+    test_diffusion_model.py:158-233) on a swiss-roll-sized model, plus what the arithmetic implies: pinned components
+    (mask 0) come back as fixed_x at every time, rows with nothing pinned follow the ordinary sampler exactly, a
+    263 000-row call spans two chunks of the batch engine, and the unsupported combinations raise."""
+    kind, cfg, m = um.build("swiss_noise", DEV)
+    rows = 12
+    data = torch.randn(rows, 2, device=DEV)
+    fixed_x = torch.tensor([1.0, 0.0], device=DEV).unsqueeze(0).expand(rows, -1)
+    fixed_mask = torch.tensor([0.0, 1.0], device=DEV).unsqueeze(0).expand(rows, -1)
+    t_span = torch.linspace(0.0, 1.0, 5)
+    f = m.sample_forward_process_with_fixed_x
+    assert tuple(f(fixed_x=fixed_x, fixed_mask=fixed_mask, t_span=t_span).shape) == (5, rows, 2)
+    assert tuple(f(fixed_x=fixed_x, fixed_mask=fixed_mask, t_span=t_span, batch_size=20).shape) == (5, 20, rows, 2)
+    assert tuple(f(fixed_x=fixed_x, fixed_mask=fixed_mask, t_span=t_span, x_0=data).shape) == (5, rows, 2)
+    x_t = f(fixed_x=fixed_x, fixed_mask=fixed_mask, t_span=t_span, batch_size=20, x_0=data)
+    assert tuple(x_t.shape) == (5, 20, rows, 2)
+    assert torch.equal(x_t[..., 0], torch.ones_like(x_t[..., 0]))          # the pinned component, at every time
+    s = m.sample_with_fixed_x
+    assert tuple(s(fixed_x=fixed_x, fixed_mask=fixed_mask, t_span=t_span).shape) == (rows, 2)
+    assert tuple(s(fixed_x=fixed_x, fixed_mask=fixed_mask, t_span=t_span, batch_size=20).shape) == (20, rows, 2)
+    assert tuple(s(fixed_x=fixed_x, fixed_mask=fixed_mask, t_span=t_span, x_0=data).shape) == (rows, 2)
+    assert tuple(s(fixed_x=fixed_x, fixed_mask=fixed_mask, t_span=t_span, batch_size=20, x_0=data).shape) == (20, rows, 2)
+    # nothing pinned: the ordinary sampler (the fp32 batch engine runs both)
+    ones = torch.ones(rows, 2, device=DEV)
+    free = f(fixed_x=fixed_x, fixed_mask=ones, t_span=t_span, x_0=data)
+    close(free, m.sample_forward_process(t_span=t_span, x_0=data), what="fixed_x with an all-ones mask", tol=1e-6)
+    # two chunks of the batch engine, against the oracle on the rows around the chunk boundary
+    big = 263000   # SAMPLE_CHUNK_ROWS = 262 144
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    x0 = torch.randn(big, 2, generator=gen)
+    fxb = torch.randn(big, 2, generator=gen)
+    mk = (torch.rand(big, 2, generator=gen) < 0.5).float()
+    noise = torch.randn(4, big, 2, generator=gen)
+    out = s(fixed_x=cu(fxb), fixed_mask=cu(mk), t_span=t_span, x_0=cu(x0), fixed_noise=cu(noise))
+    sel = torch.cat([torch.arange(0, 40), torch.arange(262144 - 20, 262144 + 20), torch.arange(big - 40, big)])
+    ref = O.sample_forward_process_with_fixed_x(gu.weights("swiss_noise"), cfg, kind, t_span, fxb[sel], mk[sel],
+                                                noise[:, sel], x_0=x0[sel])[-1]
+    close(out[sel.to(DEV)], ref, what="fixed_x 263000 rows (two chunks)")
+    with pytest.raises(NotImplementedError):
+        s(fixed_x=fixed_x, fixed_mask=fixed_mask, t_span=t_span, with_grad=True)
+    with pytest.raises(AssertionError):
+        s(fixed_x=fixed_x, fixed_mask=fixed_mask, solver_config=dict(type="DPMSolver", args=dict(
+            order=2, device=DEV, steps=5)))
+    with pytest.raises(AssertionError):
+        s(fixed_x=fixed_x, fixed_mask=fixed_mask[:3], t_span=t_span)

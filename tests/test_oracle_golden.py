@@ -173,3 +173,43 @@ def test_schedules():
             fin = np.isfinite(b)
             assert np.array_equal(np.isfinite(a), fin), gold
             np.testing.assert_allclose(a[fin], b[fin], rtol=1e-6, atol=1e-7, err_msg=pname + gold)
+
+
+FIXED_X_MODELS = ("small_vp_noise", "small_vp_score", "small_gvp_velocity", "small_uncond_noise", "small_energy", "qgpo_noise")
+
+
+@pytest.mark.parametrize("name", FIXED_X_MODELS)
+def test_sampling_with_fixed_x(name):
+    """sample_forward_process_with_fixed_x of the reference (tests/golden/make_golden_fixed_x.py): pinned, free and
+    fractionally masked components; x_0 given / drawn; extra batch sizes; guided and unguided; ODE and (where the
+    reference itself runs) Euler-Maruyama."""
+    kind, cfg, info = gu.model_info(name)
+    sd = gu.weights(name)
+    g = gu.load("fixed_x.npz")
+    pre = name + "/"
+    x0, fx, mask = gu.T(g[pre + "x0"]), gu.T(g[pre + "fixed_x"]), gu.T(g[pre + "mask"])
+    cond = gu.T(g[pre + "cond"]) if pre + "cond" in g else None
+    t_span = torch.linspace(0.0, 1.0, 7)
+    rel = name in ("small_vp_score",)
+    n = 0
+    for tag, B, use_x0 in (("x0", None, True), ("B2_x0", 2, True), ("B3_draw", 3, False)):
+        for gs in ((0.0, 1.0) if kind == "energy" else (None,)):
+            key = "%sode_%s%s" % (pre, tag, "" if gs is None else "_g%g" % gs)
+            traj = O.sample_forward_process_with_fixed_x(
+                sd, cfg, kind, t_span, fx, mask, gu.T(g["%sode_%s_noise" % (pre, tag)]), batch_size=B,
+                x_0=x0 if use_x0 else None, condition=cond, x_T=None if use_x0 else gu.T(g["%sode_%s_xT" % (pre, tag)]),
+                guidance_scale=1.0 if gs is None else gs)
+            close(traj, g[key], what=key, rtol=1e-4 if rel else 2e-5)
+            # pinned components never move, free rows follow the ordinary sampler's arithmetic
+            n += 1
+    for gs in ((0.0, 1.0) if kind == "energy" else (None,)):
+        key = "%ssde%s" % (pre, "" if gs is None else "_g%g" % gs)
+        if key not in g:
+            assert any(r.startswith(key[:-3] if gs is not None else key) or r.startswith(pre + "sde") for r in g["raises"])
+            continue
+        traj = O.sample_forward_process_with_fixed_x(
+            sd, cfg, kind, torch.linspace(0.0, 1.0, 5), fx, mask, gu.T(g[pre + "sde_noise"]), x_0=x0, condition=cond,
+            guidance_scale=1.0 if gs is None else gs, solver="SDESolver", dt=0.25, increments=gu.T(g[pre + "sde_dW"]))
+        close(traj, g[key], what=key, rtol=1e-4)
+        n += 1
+    assert n >= 3
