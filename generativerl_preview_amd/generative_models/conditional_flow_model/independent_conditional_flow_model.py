@@ -67,6 +67,28 @@ class IndependentConditionalFlowModel(nn.Module):
         data = reshape_output(self, data, batch_size, extra, n, x_0, condition)
         return data[-1] if _final_only else data
 
+    def forward_sample(self, x, t_span, condition=None, with_grad: bool = False, solver_config=None):
+        """:743-770 -- final state of ``forward_sample_process``."""
+        return self.forward_sample_process(x=x, t_span=t_span, condition=condition, with_grad=with_grad,
+                                           solver_config=solver_config, _final_only=True)
+
+    def forward_sample_process(self, x, t_span, condition=None, with_grad: bool = False, solver_config=None,
+                               _final_only=False):
+        """:772-846: encode data to the latent space -- Euler on ``t_span`` with the drift
+        ``-model(t_span.max() - t + t_span.min(), x, c)`` (:807-809); returns (T, N, D)."""
+        t_span = t_span.to(self.device)
+        if solver_config is not None:
+            solver_config = as_config(solver_config)
+            solver = get_solver(solver_config.type)(**solver_config.args)
+        else:
+            assert hasattr(self, "solver"), "solver must be specified in config or solver_config"
+            solver = self.solver
+        if not isinstance(solver, ODESolver):
+            raise NotImplementedError("Solver type {} is not implemented".format(type(solver).__name__))
+        ts = t_span.detach().to("cpu", torch.float32)
+        drift = FusedDrift("icfm_reverse", self.model, self.model_type, condition=condition, T=(ts.min(), ts.max()))
+        return solver.integrate(drift=drift, x0=x, t_span=t_span, return_trajectory=not _final_only, with_grad=with_grad)
+
     def flow_matching_loss(self, x0, x1, condition=None, average: bool = True, sum_all_elements: bool = True,
                            t=None, noise=None):
         """:678-697 -> velocity_function.py:220-302"""

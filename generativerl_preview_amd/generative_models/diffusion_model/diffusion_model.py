@@ -199,6 +199,39 @@ class DiffusionModel(nn.Module):
             data = data.squeeze(1)
         return data[-1] if _final_only else data
 
+    # ------------------------------------------------------------------ encoding (data -> latent)
+    def forward_sample(self, x, t_span: torch.Tensor, condition=None, with_grad: bool = False, solver_config=None, **kw):
+        """diffusion_model.py:861-888 -- final state of ``forward_sample_process``."""
+        return self.forward_sample_process(x=x, t_span=t_span, condition=condition, with_grad=with_grad,
+                                           solver_config=solver_config, _final_only=True, **kw)
+
+    def forward_sample_process(self, x, t_span: torch.Tensor, condition=None, with_grad: bool = False,
+                               solver_config=None, noise_increments=None, _final_only=False):
+        """diffusion_model.py:890-983: the forward (data -> latent) probability-flow ODE / forward SDE of the model,
+        integrated on ``t_span`` by the fused integrator (same kernels as sampling: only the per-step coefficients
+        differ, diffusion_process.py:559-740).  Returns (T, N, D) as the reference does (no batch bookkeeping)."""
+        t_span = t_span.to(self.device)
+        if solver_config is not None:
+            solver_config = as_config(solver_config)
+            solver = get_solver(solver_config.type)(**solver_config.args)
+        else:
+            assert hasattr(self, "solver"), "solver must be specified in config or solver_config"
+            solver = self.solver
+        if isinstance(solver, ODESolver):
+            drift = self.diffusion_process.forward_ode(function=self.model, function_type=self.model_type,
+                                                       condition=condition).drift
+            return solver.integrate(drift=drift, x0=x, t_span=t_span, return_trajectory=not _final_only, with_grad=with_grad)
+        if isinstance(solver, SDESolver):
+            assert self.diffusion_process is not None, "path must be specified in config"
+            sde = self.diffusion_process.forward_sde(
+                function=self.model, function_type=self.model_type, condition=condition,
+                forward_diffusion_function=self.diffusion_process.diffusion,
+                forward_diffusion_squared_function=self.diffusion_process.diffusion_squared)
+            return solver.integrate(drift=sde.drift, diffusion=sde.diffusion, x0=x, t_span=t_span,
+                                    noise_increments=noise_increments, return_trajectory=not _final_only,
+                                    with_grad=with_grad)
+        raise NotImplementedError("Solver type {} is not implemented".format(type(solver).__name__))
+
     # ------------------------------------------------------------------ training
     def score_matching_loss(self, x, condition=None, weighting_scheme: str = None, average: bool = True,
                             t=None, noise=None):

@@ -87,6 +87,18 @@ class DiffusionProcess:
         return SDE(drift=d, diffusion=d)
 
 
+    def forward_ode(self, function, function_type, condition=None, T=torch.tensor(1.0)):   # :672-740
+        return ODE(drift=self._fused("forward_ode", function, function_type, condition, None, T))
+
+    def forward_sde(self, function, function_type, forward_diffusion_function=None,
+                    forward_diffusion_squared_function=None, condition=None, T=torch.tensor(1.0)):  # :559-670
+        fproc = getattr(forward_diffusion_function, "__self__", None)
+        if not isinstance(fproc, DiffusionProcess):
+            raise NotImplementedError("forward_diffusion_function must be a DiffusionProcess.diffusion bound method")
+        d = self._fused("forward_sde", function, function_type, condition, fproc.path, T)
+        return SDE(drift=d, diffusion=d)
+
+
 class GuidedScore:
     """score(t,x,c) + guidance_scale * dE/dx (energy_conditional_diffusion_model.py:1109-1133) as a
     descriptor: the model head, the energy net and the scale."""

@@ -30,7 +30,7 @@ def _head_to_score(model_type, path, tau):
 
 
 class FusedDrift:
-    """kind: 'reverse_ode' | 'reverse_sde' | 'icfm'."""
+    """kind: 'reverse_ode' | 'reverse_sde' | 'icfm' | 'forward_ode' | 'forward_sde' | 'icfm_reverse'."""
 
     def __init__(self, kind, model, model_type, path=None, reverse_path=None, condition=None,
                  guidance=None, guidance_scale=0.0, T=1.0):
@@ -56,6 +56,29 @@ class FusedDrift:
         if self.kind == "icfm":
             # drift = model(t, x, c), conditional_flow_model/independent_conditional_flow_model.py:285-288
             return t, zero, torch.ones_like(t), zero, zero
+        if self.kind == "icfm_reverse":
+            # drift = -model(t_max - t + t_min, x, c), independent_conditional_flow_model.py:807-809; T = (t_min, t_max)
+            return (self.T[1] - t + self.T[0]).to(torch.float32), zero, -torch.ones_like(t), zero, zero
+        if self.kind in ("forward_ode", "forward_sde"):
+            # diffusion_process.py:559-740: the model is evaluated at the solver's own time
+            p, mt = self.path, self.model_type
+            f, g2 = p.drift_coefficient(t), p.diffusion_squared(t)
+            if self.kind == "forward_sde":
+                fp = self.reverse_path   # the process whose diffusion drives the forward SDE
+                d2, s = g2 - fp.diffusion_squared(t), fp.diffusion(t)
+                r = fp.diffusion_squared(t) / (g2 + 1e-8)
+            else:
+                d2, s, r = g2, zero, zero
+            if mt == "score_function":
+                return t, f, -0.5 * d2, zero, s
+            if mt == "noise_function":
+                return t, f, 0.5 * d2 / p.std(t), zero, s
+            if mt == "velocity_function":
+                return t, r * f, 1.0 - r, zero, s
+            if mt == "data_prediction_function":
+                D = 0.5 * d2 / p.covariance(t)
+                return t, f + D, -p.scale(t) * D, zero, s
+            raise NotImplementedError("Unknown type of function {}".format(mt))
         tau = torch.tensor(self.T, dtype=torch.float32) - t
         p, mt = self.path, self.model_type
         f, g2 = p.drift_coefficient(tau), p.diffusion_squared(tau)
@@ -114,8 +137,8 @@ class FusedDrift:
         if self.guidance is not None:
             g_plan, g_packed = self.guidance.plan, self.guidance.packed(L.F32 if dtype == L.F32 else dtype)
         if self.fixed is not None:
-            if self.kind == "icfm":
-                raise NotImplementedError("fixed-component sampling is defined for diffusion paths only")
+            if self.kind not in ("reverse_ode", "reverse_sde"):
+                raise NotImplementedError("fixed-component sampling is defined for the reverse diffusion processes only")
             fx, mask, noise = self.fixed
             tau = table[:, 0].to("cpu", torch.float32)
             fix_sc = torch.stack([self.path.scale(tau), self.path.std(tau)], 1).to(torch.float32).contiguous()

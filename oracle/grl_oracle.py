@@ -246,6 +246,52 @@ def reverse_sde_drift(model_type, path, rpath, fn, t, x, T=1.0):
     raise NotImplementedError(model_type)
 
 
+def forward_ode_drift(model_type, path, fn, t, x):
+    """DiffusionProcess.forward_ode, diffusion_process.py:672-740 (the model is evaluated at the solver time t)."""
+    f, g2 = _b(path.f(t), x), _b(path.g2(t), x)
+    if model_type == "score_function":
+        return f * x - 0.5 * g2 * fn(t, x)
+    if model_type == "noise_function":
+        return f * x + 0.5 * g2 * fn(t, x) / _b(path.std(t), x)
+    if model_type == "velocity_function":
+        return fn(t, x)
+    if model_type == "data_prediction_function":
+        D = 0.5 * g2 / _b(path.cov(t), x)
+        return (f + D) * x - _b(path.scale(t), x) * D * fn(t, x)
+    raise NotImplementedError(model_type)
+
+
+def forward_sde_drift(model_type, path, fpath, fn, t, x):
+    """DiffusionProcess.forward_sde, diffusion_process.py:559-670; ``fpath`` is the process whose diffusion drives it."""
+    f, g2, fg2 = _b(path.f(t), x), _b(path.g2(t), x), _b(fpath.g2(t), x)
+    if model_type == "score_function":
+        return f * x - 0.5 * (g2 - fg2) * fn(t, x)
+    if model_type == "noise_function":
+        return f * x + 0.5 * (g2 - fg2) * fn(t, x) / _b(path.std(t), x)
+    if model_type == "velocity_function":
+        v = fn(t, x)
+        return v - (v - f * x) * (fg2 / (g2 + 1e-8))
+    if model_type == "data_prediction_function":
+        D = 0.5 * (g2 - fg2) / _b(path.cov(t), x)
+        return (f + D) * x - _b(path.scale(t), x) * D * fn(t, x)
+    raise NotImplementedError(model_type)
+
+
+def forward_sample_process(sd, cfg, kind, x, t_span, condition=None, solver="ODESolver", dt=None, increments=None):
+    """``forward_sample_process`` of DiffusionModel (diffusion_model.py:890-983) and of
+    IndependentConditionalFlowModel (independent_conditional_flow_model.py:772-846): returns (T, N, D)."""
+    fn = lambda t, y: intrinsic_forward(sd, t, y, condition)  # noqa: E731
+    if kind == "icfm":
+        lo, hi = t_span.min(), t_span.max()
+        return euler_ode(lambda t, y: -fn(hi - t + lo, y), x, t_span)
+    path, mt = Path(cfg["path"]), cfg["model"]["type"]
+    if solver == "ODESolver":
+        return euler_ode(lambda t, y: forward_ode_drift(mt, path, fn, t, y), x, t_span)
+    return euler_maruyama(lambda t, y: forward_sde_drift(mt, path, path, fn, t, y),
+                          lambda t, y: _b(path.g(t), y) if t.dim() else path.g(t) * torch.ones_like(y),
+                          x, t_span, dt, increments)
+
+
 def reverse_sde_diffusion(rpath, t, x, T=1.0):
     """diffusion_process.py:775-779 -- g_rev(T - t) broadcast to x."""
     return _b(rpath.g(T - t), x)

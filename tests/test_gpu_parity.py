@@ -720,3 +720,44 @@ def test_sampling_with_fixed_x_shapes_and_invariants():
             order=2, device=DEV, steps=5)))
     with pytest.raises(AssertionError):
         s(fixed_x=fixed_x, fixed_mask=fixed_mask[:3], t_span=t_span)
+
+
+FORWARD_MODELS = ("small_vp_noise", "small_vp_score", "small_vp_velocity", "small_vp_data", "small_gvp_velocity",
+                  "small_uncond_noise", "small_icfm", "swiss_noise", "icfm_cond")
+
+
+@pytest.mark.parametrize("name", FORWARD_MODELS)
+def test_forward_sample_vs_golden(name):
+    """forward_sample / forward_sample_process (data -> latent; the fused integrator with the coefficients of
+    DiffusionProcess.forward_ode / forward_sde, or the ICFM's reversed flow) against the reference's trajectories."""
+    kind, cfg, m = um.build(name, DEV)
+    g = gu.load("forward.npz")
+    pre = name + "/"
+    x = cu(g[pre + "x"])
+    cond = cu(g[pre + "cond"]) if pre + "cond" in g else None
+    t_span = torch.linspace(0.05, 1.0, 8)
+    traj = m.forward_sample_process(x=x, t_span=t_span, condition=cond)
+    close(traj, g[pre + "ode"], what=pre + "ode", rel=True)
+    close(m.forward_sample(x=x, t_span=t_span, condition=cond), g[pre + "ode"][-1], what=pre + "ode final", rel=True)
+    if pre + "sde" in g:
+        traj = m.forward_sample_process(x=x, t_span=torch.tensor([0.05, 0.3, 0.55, 0.8, 1.0]), condition=cond,
+                                        noise_increments=cu(g[pre + "sde_dW"]),
+                                        solver_config=dict(type="SDESolver", args=dict(library="torchsde", dt=0.25)))
+        close(traj, g[pre + "sde"], what=pre + "sde", rel=True)
+    if name in ("swiss_noise", "icfm_cond"):   # [512,256,128]: the persistent fused bf16 integrator, other coefficients
+        m.model.compute_dtype = L.BF16
+        close(m.forward_sample_process(x=x, t_span=t_span, condition=cond), g[pre + "ode"], tol=2e-2,
+              what=pre + "ode bf16", rel=True)
+        assert m.model.plan.fused_kernel()
+
+
+def test_forward_sample_then_sample_round_trip():
+    """Encoding then decoding with the same model and grid returns close to the data (Euler both ways, 200 steps): the
+    two directions use one network and mirrored coefficients."""
+    kind, cfg, m = um.build("icfm_cond", DEV)
+    g = gu.load("forward.npz")
+    x, cond = cu(g["icfm_cond/x"]), cu(g["icfm_cond/cond"])
+    t_span = torch.linspace(0.0, 1.0, 201)
+    z = m.forward_sample(x=x, t_span=t_span, condition=cond)
+    back = m.sample(t_span=t_span, x_0=z, condition=cond)
+    close(back, x, tol=1e-3, what="icfm encode -> decode round trip")

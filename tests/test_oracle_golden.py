@@ -213,3 +213,27 @@ def test_sampling_with_fixed_x(name):
         close(traj, g[key], what=key, rtol=1e-4)
         n += 1
     assert n >= 3
+
+
+FORWARD_MODELS = ("small_vp_noise", "small_vp_score", "small_vp_velocity", "small_vp_data", "small_gvp_velocity",
+                  "small_uncond_noise", "small_icfm", "swiss_noise", "icfm_cond")
+
+
+@pytest.mark.parametrize("name", FORWARD_MODELS)
+def test_forward_sample_process(name):
+    """forward_sample_process of the reference (tests/golden/make_golden_forward.py): the data -> latent direction of
+    every head on both paths, the ICFM's reversed flow, and the forward SDE where the reference itself runs."""
+    kind, cfg, info = gu.model_info(name)
+    sd = gu.weights(name)
+    g = gu.load("forward.npz")
+    pre = name + "/"
+    x = gu.T(g[pre + "x"])
+    cond = gu.T(g[pre + "cond"]) if pre + "cond" in g else None
+    traj = O.forward_sample_process(sd, cfg, kind, x, torch.linspace(0.05, 1.0, 8), cond)
+    close(traj, g[pre + "ode"], what=pre + "ode", rtol=1e-4)
+    if pre + "sde" in g:
+        traj = O.forward_sample_process(sd, cfg, kind, x, torch.tensor([0.05, 0.3, 0.55, 0.8, 1.0]), cond,
+                                        solver="SDESolver", dt=0.25, increments=gu.T(g[pre + "sde_dW"]))
+        close(traj, g[pre + "sde"], what=pre + "sde", rtol=1e-4)
+    elif kind == "diffusion":
+        assert any(r.startswith(pre + "sde") for r in g["raises"])
