@@ -92,7 +92,35 @@ class IndependentConditionalFlowModel(nn.Module):
     def flow_matching_loss(self, x0, x1, condition=None, average: bool = True, sum_all_elements: bool = True,
                            t=None, noise=None):
         """:678-697 -> velocity_function.py:220-302"""
-        if not sum_all_elements:
-            raise NotImplementedError("element-wise (sum_all_elements=False) losses are not fused")
         t, x_t, alpha, beta, target = prepare_icfm(self.stochastic_process, x0, x1, t, noise)
+        if not sum_all_elements and not average:
+            # element-wise loss (velocity_function.py:248-253): the differentiable HIP forward (grlhip_net_backward
+            # behind autograd) and the squared error per element in torch
+            return 0.5 * (self.model(t, x_t, condition) - target) ** 2
         return fused_loss(self.model, t, x_t, condition, alpha, beta, target, average)
+
+    def flow_matching_loss_with_mask(self, x0, x1, condition=None, mask=None, average: bool = True, t=None, noise=None):
+        """:699-741: the element-wise loss with the elements outside ``mask`` (bool, (B, D)) dropped, averaged per row
+        over the kept elements (at least 1).  ``mask=None``: the ordinary loss (the reference's call on that branch
+        passes the model as ``x0`` and raises)."""
+        if mask is None:
+            return self.flow_matching_loss(x0, x1, condition, average, t=t, noise=noise)
+        loss = self.flow_matching_loss(x0, x1, condition, average=False, sum_all_elements=False, t=t, noise=noise)
+        loss = loss.masked_fill(~mask, 0.0)
+        num = torch.clamp(mask.sum(dim=tuple(range(1, mask.dim()))), min=1)
+        loss = loss.sum(dim=tuple(range(1, loss.dim()))) / num
+        return loss.mean() if average else loss
+
+    def sample_with_mask(self, t_span=None, batch_size=None, x_0=None, condition=None, mask=None, x_1=None,
+                         with_grad: bool = False, solver_config=None):
+        """:121-168 -- final state of ``sample_with_mask_forward_process``."""
+        return self.sample_with_mask_forward_process(t_span=t_span, batch_size=batch_size, x_0=x_0, condition=condition,
+                                                     mask=mask, x_1=x_1, with_grad=with_grad,
+                                                     solver_config=solver_config)[-1]
+
+    def sample_with_mask_forward_process(self, t_span=None, batch_size=None, x_0=None, condition=None, mask=None,
+                                         x_1=None, with_grad: bool = False, solver_config=None):
+        """:452-513: the sampled trajectory with the elements under ``mask`` replaced by ``x_1``."""
+        data = self.sample_forward_process(t_span=t_span, batch_size=batch_size, x_0=x_0, condition=condition,
+                                           with_grad=with_grad, solver_config=solver_config)
+        return data if mask is None else torch.where(mask, x_1, data)

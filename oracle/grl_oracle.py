@@ -515,6 +515,18 @@ def icfm_flow_matching_loss(net_fn, x0, x1, t, eps, sigma, average=True):
     return _row_loss(net_fn(t, x_t), x1 - x0, average)
 
 
+def icfm_flow_matching_loss_with_mask(net_fn, x0, x1, t, eps, sigma, mask, average=True):
+    """IndependentConditionalFlowModel.flow_matching_loss_with_mask, independent_conditional_flow_model.py:699-741:
+    element-wise loss (velocity_function.py:248-253), elements outside the mask dropped, per-row mean over the kept
+    elements (at least 1)."""
+    tb = _b(t, x0)
+    x_t = x0 * (1.0 - tb) + x1 * tb + sigma * eps
+    v = net_fn(t, x_t)
+    el = 0.5 * (v - (x1 - x0)) * (v - (x1 - x0))
+    loss = el.masked_fill(~mask, 0.0).sum(1) / torch.clamp(mask.sum(1), min=1)
+    return (loss.mean() if average else loss), el
+
+
 # ----------------------------------------------------------------------------- DPM-Solver
 def dpm_orders_singlestep(steps, order):
     """get_orders_for_singlestep_solver, numerical_solvers/dpm_solver.py:163-230."""

@@ -237,3 +237,23 @@ def test_forward_sample_process(name):
         close(traj, g[pre + "sde"], what=pre + "sde", rtol=1e-4)
     elif kind == "diffusion":
         assert any(r.startswith(pre + "sde") for r in g["raises"])
+
+
+@pytest.mark.parametrize("name", ["small_icfm", "icfm_cond"])
+def test_icfm_masked_loss_and_sampling(name):
+    """flow_matching_loss_with_mask (+ its element-wise loss) and sample_with_mask of the reference
+    (tests/golden/make_golden_icfm_mask.py)."""
+    kind, cfg, info = gu.model_info(name)
+    sd = gu.weights(name)
+    g = gu.load("icfm_mask.npz")
+    pre = name + "/"
+    x0, x1, cond, mask = (gu.T(g[pre + k]) for k in ("x0", "x1", "cond", "mask"))
+    fn = lambda t, y: O.intrinsic_forward(sd, t, y, cond)  # noqa: E731
+    sigma = cfg["path"]["sigma"]
+    loss, el = O.icfm_flow_matching_loss_with_mask(fn, x0, x1, gu.T(g[pre + "t"]), gu.T(g[pre + "eps"]), sigma, mask)
+    close(loss, g[pre + "loss"], what="masked loss")
+    close(el, g[pre + "loss_elements"], what="element-wise loss")
+    rows, _ = O.icfm_flow_matching_loss_with_mask(fn, x0, x1, gu.T(g[pre + "t"]), gu.T(g[pre + "eps"]), sigma, mask, average=False)
+    close(rows, g[pre + "loss_rows"], what="masked loss rows")
+    traj = O.sample_forward_process(sd, cfg, "icfm", torch.linspace(0.0, 1.0, 6), x_0=x0, condition=cond)
+    close(torch.where(mask, x1, traj), g[pre + "sample_traj"], what="sample_with_mask")
