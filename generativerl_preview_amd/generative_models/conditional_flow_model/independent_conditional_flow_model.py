@@ -67,6 +67,31 @@ class IndependentConditionalFlowModel(nn.Module):
         data = reshape_output(self, data, batch_size, extra, n, x_0, condition)
         return data[-1] if _final_only else data
 
+    def log_prob(self, x_1, log_prob_x_0=None, function_log_prob_x_0=None, condition=None, t=None,
+                 using_Hutchinson_trace_estimator: bool = True, noise=None):
+        """:515-631: log-likelihood of ``x_1`` -- Euler on ``t`` (default linspace(0, 1, 1000)) of the composite ODE
+        d(x, logp)/dt = (f, -div f), f = -model(1 - t, x, c), then the prior's log-density at the reached x_0
+        (``log_prob_x_0`` given, ``function_log_prob_x_0(x_0)``, or a standard normal).  The network forward and the
+        vector-Jacobian products of the divergence are library calls (generative_models/metric.py); ``noise`` pins the
+        Hutchinson probes."""
+        from ..metric import integrate_with_divergence, standard_normal_log_prob
+        drift = FusedDrift("icfm_reverse", self.model, self.model_type, condition=condition,
+                           T=(torch.tensor(0.0), torch.tensor(1.0)))
+        t_span = torch.linspace(0.0, 1.0, 1000) if t is None else t
+        x0, diff = integrate_with_divergence(drift, x_1, t_span, condition, using_Hutchinson_trace_estimator, noise)
+        if log_prob_x_0 is None:
+            x0 = x0.reshape(x_1.shape)
+            log_prob_x_0 = function_log_prob_x_0(x0) if function_log_prob_x_0 is not None else standard_normal_log_prob(x0)
+        return log_prob_x_0 - diff
+
+    def sample_with_log_prob(self, t_span=None, batch_size=None, x_0=None, condition=None, with_grad: bool = False,
+                             solver_config=None, using_Hutchinson_trace_estimator: bool = True):
+        """:633-676"""
+        x = self.sample(t_span=t_span, batch_size=batch_size, x_0=x_0, condition=condition, with_grad=with_grad,
+                        solver_config=solver_config)
+        return x, self.log_prob(x_1=x, condition=condition, t=t_span,
+                                using_Hutchinson_trace_estimator=using_Hutchinson_trace_estimator)
+
     def forward_sample(self, x, t_span, condition=None, with_grad: bool = False, solver_config=None):
         """:743-770 -- final state of ``forward_sample_process``."""
         return self.forward_sample_process(x=x, t_span=t_span, condition=condition, with_grad=with_grad,

@@ -232,6 +232,24 @@ class DiffusionModel(nn.Module):
                                     with_grad=with_grad)
         raise NotImplementedError("Solver type {} is not implemented".format(type(solver).__name__))
 
+    # ------------------------------------------------------------------ likelihood
+    def log_prob(self, x=None, condition=None, using_Hutchinson_trace_estimator: bool = True, with_grad: bool = False,
+                 t=None, noise=None):
+        """diffusion_model.py:1125-1159 -> metric.py:14-139.  ``t`` (the integration grid, default
+        linspace(1e-3, 1, 1000)) and ``noise`` (the Hutchinson probes) are supersets for reproducibility."""
+        if with_grad:
+            raise NotImplementedError("log_prob(with_grad=True) needs second derivatives of the network")
+        from ..metric import compute_likelihood
+        return compute_likelihood(self, x, t=t, condition=condition,
+                                  using_Hutchinson_trace_estimator=using_Hutchinson_trace_estimator, noise=noise)
+
+    def sample_with_log_prob(self, t_span: torch.Tensor, batch_size=None, condition=None, with_grad: bool = False,
+                             solver_config=None):
+        """diffusion_model.py:1161-1189"""
+        x = self.sample_forward_process(t_span=t_span, batch_size=batch_size, condition=condition, with_grad=with_grad,
+                                        solver_config=solver_config)[-1]
+        return x, self.log_prob(x=x, condition=condition, with_grad=with_grad)
+
     # ------------------------------------------------------------------ training
     def score_matching_loss(self, x, condition=None, weighting_scheme: str = None, average: bool = True,
                             t=None, noise=None):

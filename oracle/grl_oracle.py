@@ -527,6 +527,42 @@ def icfm_flow_matching_loss_with_mask(net_fn, x0, x1, t, eps, sigma, mask, avera
     return (loss.mean() if average else loss), el
 
 
+def log_likelihood(sd, cfg, kind, x, t_span, condition=None, hutchinson=True, probes=None):
+    """compute_likelihood (grl/generative_models/metric.py:14-139) / IndependentConditionalFlowModel.log_prob
+    (independent_conditional_flow_model.py:515-631): Euler on t_span of d(x, logp)/dt = (f, -div f) with
+    f = forward_ode drift (diffusion) or -model(1 - t, x, c) (flow), div f exact (one autograd product per dimension,
+    metric.py:56-76) or Hutchinson-Skilling with the Gaussian probes ``probes[k]`` (metric.py:78-84), then the standard
+    normal log-density at the end point minus the accumulated difference."""
+    fn = lambda t, y: intrinsic_forward(sd, t, y, condition)  # noqa: E731
+    if kind == "icfm":
+        drift = lambda t, y: -fn(1.0 - t, y)  # noqa: E731
+    else:
+        path, mt = Path(cfg["path"]), cfg["model"]["type"]
+        drift = lambda t, y: forward_ode_drift(mt, path, fn, t, y)  # noqa: E731
+    x = x.clone()
+    diff = torch.zeros(x.shape[0])
+    for k in range(len(t_span) - 1):
+        tk = t_span[k].repeat(x.shape[0])
+        with torch.enable_grad():
+            xt = x.detach().requires_grad_(True)
+            dx = drift(tk, xt)
+            if hutchinson:
+                eps = probes[k]
+                g = torch.autograd.grad(torch.sum(dx * eps), xt)[0]
+                div = torch.sum(g * eps, dim=1)
+            else:
+                div = torch.zeros(x.shape[0])
+                for i in range(x.shape[1]):
+                    go = torch.zeros_like(xt)
+                    go[:, i] = 1
+                    div = div + torch.autograd.grad(dx, xt, grad_outputs=go, retain_graph=True)[0][:, i]
+        dt = t_span[k + 1] - t_span[k]
+        diff = diff + dt * (-div.detach())
+        x = x + dt * dx.detach()
+    logp_end = -0.5 * (x * x).sum(1) - 0.5 * x.shape[1] * math.log(2.0 * math.pi)
+    return logp_end - diff
+
+
 # ----------------------------------------------------------------------------- DPM-Solver
 def dpm_orders_singlestep(steps, order):
     """get_orders_for_singlestep_solver, numerical_solvers/dpm_solver.py:163-230."""

@@ -54,6 +54,13 @@ def _install_standins():
 
     # ---- integrators (specification, see module docstring) ----
     def euler_fixed_grid(f, x, t_span):
+        if isinstance(x, tuple):   # torchdiffeq integrates tuples of tensors component-wise and returns a tuple
+            traj = [x]
+            for k in range(len(t_span) - 1):
+                dx = f(t_span[k], x)
+                x = tuple(xi + (t_span[k + 1] - t_span[k]) * di for xi, di in zip(x, dx))
+                traj.append(x)
+            return tuple(torch.stack([s[i] for s in traj]) for i in range(len(x)))
         traj = [x]
         for k in range(len(t_span) - 1):
             x = x + (t_span[k + 1] - t_span[k]) * f(t_span[k], x)

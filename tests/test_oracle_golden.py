@@ -257,3 +257,21 @@ def test_icfm_masked_loss_and_sampling(name):
     close(rows, g[pre + "loss_rows"], what="masked loss rows")
     traj = O.sample_forward_process(sd, cfg, "icfm", torch.linspace(0.0, 1.0, 6), x_0=x0, condition=cond)
     close(torch.where(mask, x1, traj), g[pre + "sample_traj"], what="sample_with_mask")
+
+
+LOGPROB_MODELS = ("small_vp_noise", "small_vp_score", "small_gvp_velocity", "small_uncond_noise", "small_icfm")
+
+
+@pytest.mark.parametrize("name", LOGPROB_MODELS)
+def test_log_likelihood(name):
+    """compute_likelihood / log_prob of the reference (tests/golden/make_golden_logprob.py): exact trace and
+    Hutchinson-Skilling estimator with replayed probes."""
+    kind, cfg, info = gu.model_info(name)
+    sd = gu.weights(name)
+    g = gu.load("logprob.npz")
+    pre = name + "/"
+    x, grid = gu.T(g[pre + "x"]), gu.T(g[pre + "grid"])
+    cond = gu.T(g[pre + "cond"]) if pre + "cond" in g else None
+    close(O.log_likelihood(sd, cfg, kind, x, grid, cond, hutchinson=False), g[pre + "exact"], what="exact", rtol=2e-4)
+    close(O.log_likelihood(sd, cfg, kind, x, grid, cond, probes=gu.T(g[pre + "probes"])), g[pre + "hutchinson"],
+          what="hutchinson", rtol=2e-4)
