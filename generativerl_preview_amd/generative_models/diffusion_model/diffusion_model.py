@@ -251,6 +251,29 @@ class DiffusionModel(nn.Module):
         return x, self.log_prob(x=x, condition=condition, with_grad=with_grad)
 
     # ------------------------------------------------------------------ training
+    def dpo_loss(self, ref_dm, data, beta, t=None, noise=None):
+        """diffusion_model.py:1191-1233 (marked in-development there): Direct Preference Optimisation on pairs
+        ``data = [x_w | x_l]`` (the first two columns win, the rest lose -- as written) against a frozen reference
+        model.  The four network evaluations are the differentiable HIP forward (gradients reach this model's
+        parameters through grlhip_net_backward; the reference model's terms are detached as in the reference).
+        Supersets ``t`` / ``noise`` pin the draws (made in the reference's order: noise first, then t)."""
+        x_w, x_l = data[:, :2], data[:, 2:]
+        if noise is None:
+            noise = torch.randn_like(x_w)
+        eps = 1e-5
+        if t is None:
+            t = torch.rand(x_w.shape[0], device=x_w.device) * (self.diffusion_process.t_max - eps) + eps
+        dp = self.diffusion_process
+        noisy_w = dp.scale(t, x_w) * x_w + dp.std(t, x_w) * noise
+        noisy_l = dp.scale(t, x_l) * x_l + dp.std(t, x_l) * noise
+        err = lambda net, x: (net(t, x) - noise).norm(dim=1, keepdim=True).pow(2)   # noqa: E731
+        with torch.no_grad():
+            ref_w, ref_l = err(ref_dm.model, noisy_w), err(ref_dm.model, noisy_l)
+        w_diff = err(self.model, noisy_w) - ref_w
+        l_diff = err(self.model, noisy_l) - ref_l
+        inside = -1 * beta * (w_diff - l_diff)
+        return -1 * torch.log(torch.sigmoid(inside) + eps).mean()
+
     def score_matching_loss(self, x, condition=None, weighting_scheme: str = None, average: bool = True,
                             t=None, noise=None):
         """diffusion_model.py:1006-1041 -> score_function.py:83-251.  ``t`` / ``noise`` (superset)

@@ -836,3 +836,33 @@ def test_log_prob_vs_golden(name):
         ones = m.log_prob(x_1=x, condition=cond, t=grid, using_Hutchinson_trace_estimator=False,
                           function_log_prob_x_0=lambda z: torch.ones(z.shape[0], device=DEV))
         close(ones - with_prior, torch.ones(x.shape[0]), tol=1e-5, what="prior log-density options")
+
+
+def test_dpo_loss_vs_golden():
+    """DiffusionModel.dpo_loss against the reference (loss 1e-5 relative, every parameter gradient): the four network
+    evaluations are the differentiable HIP forward."""
+    kind, cfg, m = um.build("swiss_noise", DEV)
+    _, _, ref = um.build("swiss_noise", DEV)
+    g = gu.load("dpo.npz")
+    w = gu.weights("swiss_noise", as_torch=False)
+    gen = torch.Generator().manual_seed(4242)   # tests/golden/make_golden_dpo.py: the frozen model's perturbation
+    sd = {k: torch.from_numpy(np.asarray(v)) + 0.02 * torch.randn(np.asarray(v).shape, generator=gen) * (0.0 if k.endswith("t_encoder.W") else 1.0)
+          for k, v in w.items()}
+    assert abs(sum(float(v.double().sum()) for v in sd.values()) - float(g["ref_checksum"])) < 1e-6 * abs(float(g["ref_checksum"])) + 1e-6
+    ref.load_state_dict(sd)
+    ref = ref.to(DEV)
+    m.zero_grad(set_to_none=True)
+    loss = m.dpo_loss(ref, cu(g["data"]), float(g["beta"]), t=cu(g["t"]), noise=cu(g["noise"]))
+    want = float(g["loss"])
+    assert abs(float(loss) - want) <= 1e-5 * abs(want) + 1e-7, (float(loss), want)
+    loss.backward()
+    n = 0
+    for k, p in m.named_parameters():
+        if "gradsub/" + k in g and not k.endswith("t_encoder.W"):
+            flat = p.grad.reshape(-1)
+            close(flat[:: max(1, flat.numel() // 509)][:509], g["gradsub/" + k], tol=2e-4, what="dpo grad " + k, rel=True)
+            s = g["gradsum/" + k]
+            assert abs(float(flat.double().pow(2).sum().sqrt()) - s[1]) <= 2e-4 * s[1] + 1e-7, k
+            n += 1
+    assert n > 10
+    assert all(p.grad is None for p in ref.parameters())
