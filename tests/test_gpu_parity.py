@@ -866,3 +866,49 @@ def test_dpo_loss_vs_golden():
             n += 1
     assert n > 10
     assert all(p.grad is None for p in ref.parameters())
+
+
+def test_sample_fixed_c_abi_dtypes_and_edges():
+    """grlhip_sample_fixed through NetPlan.sample_fixed: GRLHIP_BF16 on a net without a fused integrator (batch engine,
+    bf16 MFMAs) within the bf16 tolerance of the oracle; a net whose bf16 image belongs to the fused integrator is
+    refused; zero steps return the blended initial state; zero rows are a no-op; a null mask is an argument error."""
+    from generativerl_preview_amd.generative_models.fused import FusedDrift
+    kind, cfg, m = um.build("small_gvp_velocity", DEV)
+    g = gu.load("fixed_x.npz")
+    pre = "small_gvp_velocity/"
+    x0, fx, mask, cond = cu(g[pre + "x0"]), cu(g[pre + "fixed_x"]), cu(g[pre + "mask"]), cu(g[pre + "cond"])
+    noise = cu(g[pre + "ode_x0_noise"])
+    t_span = torch.linspace(0.0, 1.0, 7)
+    net = m.model
+    drift = FusedDrift("reverse_ode", net, m.model_type, m.path, condition=cond)
+    ts = t_span.to("cpu", torch.float32)
+    table = drift.table(ts[:-1], ts[1:] - ts[:-1], torch.arange(1, 7), torch.ones(6))
+    tau = table[:, 0]
+    fix_sc = torch.stack([m.path.scale(tau), m.path.std(tau)], 1).float().contiguous()
+    assert net.plan.fused_kernel() == ""
+    final, traj = net.plan.sample_fixed(net.packed(L.BF16), x0, cond, table, fx, mask, fix_sc, fix_noise=noise,
+                                        trajectory_slots=7, dtype=L.BF16)
+    close(traj, g[pre + "ode_x0"], tol=BF16_TOL, what="sample_fixed bf16 batch engine")
+    exact, _ = net.plan.sample_fixed(net.packed(L.F32), x0, cond, table, fx, mask, fix_sc, fix_noise=noise)
+    assert float((final - exact).abs().max()) > 0.0
+    # zero steps: the blended initial state
+    zf, zt = net.plan.sample_fixed(net.packed(L.F32), x0, cond, table[:0], fx, mask, fix_sc[:0], trajectory_slots=1)
+    close(zf, fx * (1 - mask) + x0 * mask, tol=0.0, what="sample_fixed zero steps")
+    close(zt[0], zf, tol=0.0, what="sample_fixed zero steps slot 0")
+    # zero rows
+    ef, _ = net.plan.sample_fixed(net.packed(L.F32), x0[:0], cond[:0], table, fx[:0], mask[:0], fix_sc)
+    assert tuple(ef.shape) == (0, 6)
+    # the fused integrator's image is refused
+    kind2, cfg2, m2 = um.build("swiss_noise", DEV)
+    n2 = m2.model
+    assert n2.plan.fused_kernel()
+    d2 = FusedDrift("reverse_ode", n2, m2.model_type, m2.path)
+    tab2 = d2.table(ts[:-1], ts[1:] - ts[:-1], torch.arange(1, 7), torch.ones(6))
+    z = torch.zeros(4, 2, device=DEV)
+    with pytest.raises(L.GrlHipError, match="fused"):
+        n2.plan.sample_fixed(n2.packed(L.BF16), z, None, tab2, z, z, fix_sc, dtype=L.BF16)
+    # null mask
+    rc = L.lib().grlhip_sample_fixed(n2.plan.handle, n2.packed(L.F32).data_ptr(), L.F32, None, None, z.data_ptr(), None,
+                                     tab2.to(DEV).data_ptr(), None, 6, 4, z.data_ptr(), None, fix_sc.to(DEV).data_ptr(), None,
+                                     z.data_ptr(), None, None, 0, None)
+    assert rc == -1   # GRLHIP_ERR_INVALID
