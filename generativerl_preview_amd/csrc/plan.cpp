@@ -172,7 +172,7 @@ Plan* build_plan(const grlhip_net_desc& d, std::string& err) {
       p->tr_gtc = t.alloc(d.t_dim + ch);
       const int g_zc = cond ? t.alloc(ch) : -1;
       const int hmax_t = *std::max_element(h, h + L_);
-      const int g_h1 = t.alloc(hmax_t), g_z = t.alloc(hmax_t), sM = t.alloc(hmax_t);
+      const int g_h1 = t.alloc(hmax_t), g_z = t.alloc(hmax_t), g_z1 = t.alloc(hmax_t), sM = t.alloc(hmax_t);
 
       struct Blk { int lt, l1, ld, lm, in, K, out, N, T, z1, h1, z2; };
       std::vector<Blk> blks;
@@ -214,13 +214,13 @@ Plan* build_plan(const grlhip_net_desc& d, std::string& err) {
         }
         t.eltwise(TB, OP_SILU_BWD, k.N, k.z2, g_z, gout);       // dz2 = dout * silu'(z2)
         dw(k.ld, g_z, k.h1);
-        lin_t(k.ld, g_z, g_h1, false);                            // dh1 (= dT)
+        // dh1 (= dT) and, from the same epilogue, dz1 = dh1 * silu'(z1) (g_z is this GEMM's input: dz1 -> g_z1)
+        t.linear(TB, T_of(k.ld), g_z, g_h1, k.z1, F_DSILU, g_z1);
         dw(k.lt, g_h1, ste_t);
         lin_t(k.lt, g_h1, g_ste, ste_written);
         ste_written = true;
-        t.eltwise(TB, OP_SILU_BWD, k.N, k.z1, g_z, g_h1);        // dz1 = dh1 * silu'(z1)
-        dw(k.l1, g_z, k.in);
-        if (gin_mode) lin_t(k.l1, g_z, gin, true);
+        dw(k.l1, g_z1, k.in);
+        if (gin_mode) lin_t(k.l1, g_z1, gin, true);
       };
       const int llast = b.by_name["backbone.last_block"];
       dw(llast, p->tr_gout, catf[0]);
@@ -245,14 +245,14 @@ Plan* build_plan(const grlhip_net_desc& d, std::string& err) {
         dw(b.by_name["backbone.pre_sort_condition.0"], g_zc, p->tr_c);
       }
       // ---- input gradient (differentiable sampling only; skipped by the loss entry points): the first block's
-      // output gradient is still in gcat[0] + h[0] and its dz1 in g_z (nothing after that block writes them)
+      // output gradient is still in gcat[0] + h[0] and its dz1 in g_z1 (nothing after that block writes them)
       {
         const Blk& k = blks[0];
         p->tr_gx = t.alloc(d.x_dim);
         const size_t before = TB.size();
         if (k.lm >= 0) lin_t(k.lm, gcat[0] + h[0], p->tr_gx, false);
         else t.eltwise(TB, OP_COPY, k.N, gcat[0] + h[0], p->tr_gx);
-        lin_t(k.l1, g_z, p->tr_gx, true);
+        lin_t(k.l1, g_z1, p->tr_gx, true);
         p->train_bwd_dx_ops = (int32_t)(TB.size() - before);
       }
       p->train_slab_features = up(t.bump, 2);

@@ -26,7 +26,10 @@ enum OpType : int32_t {
   OP_ADD = 6,            // out[n] += in[n]
   OP_RELU_BWD = 7        // out[n] = slab[add + n] * (in[n] > 0)
 };
-enum OpFlags : int32_t { F_SILU_OUT = 1, F_SAVE_PRE = 2, F_ACCUM = 4, F_RELU_OUT = 8 };
+enum OpFlags : int32_t { F_SILU_OUT = 1, F_SAVE_PRE = 2, F_ACCUM = 4, F_RELU_OUT = 8,
+                         // backward: besides out = A in (+bias), pre = out * SiLU'(slab[add]) -- the dZ of the layer below,
+                         // whose pre-activation sits at `add` (nothing is added to out)
+                         F_DSILU = 16 };
 
 struct Op {
   int32_t type, K, N, w, b, in, out, add, flags, pre;  // pre: where z (pre-activation) is kept (F_SAVE_PRE)
