@@ -186,20 +186,22 @@ def secondary_results(device, model):
         cfg["model"] = dict(cfg["model"], type="velocity_function")
         torch.manual_seed(0)
         m3 = G.IndependentConditionalFlowModel(cfg).to(device)
+        from generativerl_preview_amd.distributed import attach_flat_grads
+        fg = attach_flat_grads(m3.model)   # every .grad is a view of ONE flat buffer: one zero, one all-reduce when N>1
         opt = torch.optim.Adam(m3.parameters(), lr=1e-4)
         B = 65536
         x1 = torch.rand(B, 6, device=device, generator=gen) * 2 - 1
         cond = torch.randn(B, 17, device=device, generator=gen)
 
         def train_step():
-            opt.zero_grad(set_to_none=False)
+            fg.zero()
             loss = m3.flow_matching_loss(torch.randn(B, 6, device=device, generator=gen), x1, cond)
             loss.backward()
             opt.step()
             return loss
-        for _ in range(2):
+        for _ in range(5):
             train_step()
-        dt, loss = _time_gpu(train_step, 10)
+        dt, loss = _time_gpu(train_step, 20)
         tf = B * 9759936 / dt / 1e12
         entry = {"name": "C3_icfm_train", "workload": "C3 GMPO ICFM flow_matching_loss fwd+bwd+Adam, batch %d, 1 GPU" % B,
                  "dtype": "f32", "value": B / dt, "unit": "rows/s", "ms_per_step": dt * 1e3, "final_loss": float(loss.detach()),
