@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static check of the inline-asm tile loads of k_bt_gemm_x6 / k_bt_dw_x6 (csrc/engine_batch.hip.inc).
+"""Static check of the inline-asm tile loads of k_bt_gemm_x6 / k_bt_dw_x6 / k_bt_gemm_bf16_big (csrc/engine_batch.hip.inc).
 
 The loads are issued by `asm volatile("global_load_dwordx4 ...")` and waited for by an explicit `s_waitcnt vmcnt(N)`,
 so the compiler does not know their destination registers are in flight.  If it places a copy (or any other use) of
@@ -109,7 +109,7 @@ def main():
             text = open(out).read()
     failed = False
     seen = 0
-    for m in re.finditer(r"^(_ZN6grlhip2bt(?:12k_bt_gemm_x6|10k_bt_dw_x6)\w+):[^\n]*\n", text, re.M):
+    for m in re.finditer(r"^(_ZN6grlhip2bt(?:12k_bt_gemm_x6|10k_bt_dw_x6|18k_bt_gemm_bf16_big)\w+):[^\n]*\n", text, re.M):
         name = m.group(1)
         end = text.index(".end_amdhsa_kernel", m.end())
         body = text[m.end():end]

@@ -337,6 +337,26 @@ def test_bf16_generic_shapes_run_on_the_batch_engine(name, rows, steps):
     assert float((got - exact).abs().max()) > 0.0, "bf16 path returned the fp32 result bit for bit: not the bf16 kernels"
 
 
+def test_bf16_wide_layers_256_tiles_match_the_128_tiles_bit_for_bit():
+    """C5's [1024] net at 65 536 rows: its 1024-wide layers run k_bt_gemm_bf16_big (256 x 256 tiles, chosen when the
+    grid fills the chip twice over); at 1 024 rows the same layers run the 128 x 128 kernel.  Same bf16 fragments, same
+    k order, rows are independent: the first 1 024 rows of the big batch must equal the small batch BIT FOR BIT, and the
+    small batch is the one the oracle test above covers.  Also a ragged row count (65 536 + 300: the padded slab)."""
+    kind, cfg, m, sd = _bf16_model("gvp_wide")
+    gen = torch.Generator().manual_seed(23)
+    rows = 65536 + 300
+    x0 = torch.randn(rows, cfg["x_size"], generator=gen).to(DEV)
+    t_span = torch.linspace(0.0, 1.0, 6)
+    small = m.sample(t_span=t_span, x_0=x0[:1024].contiguous())
+    big = m.sample(t_span=t_span, x_0=x0[:65536].contiguous())
+    ragged = m.sample(t_span=t_span, x_0=x0)
+    assert torch.isfinite(big).all() and float(big.abs().max()) > 0
+    assert torch.equal(big[:1024], small)
+    assert torch.equal(ragged[:65536], big)
+    want = O.sample_forward_process(sd, cfg, kind, t_span, x_0=x0[65536 - 64:65536 + 64].cpu())[-1]
+    close(ragged[65536 - 64:65536 + 64].cpu(), want, tol=BF16_TOL, what="bf16 256-tile kernel, rows around 65536")
+
+
 @pytest.mark.parametrize("x_dim,c_dim,guided", [(1, 5, False), (16, 32, True), (16, 33, False), (8, 16, True), (5, 67, False),
                                                  (16, None, False), (1, None, False)])
 def test_bf16_fused_kernel_at_the_edges_of_its_shape_classes(x_dim, c_dim, guided):
