@@ -21,7 +21,12 @@ m5 = G.DiffusionModel(cfg).to(device)
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
 x0 = torch.randn(rows, 64, device=device)
 t_span = torch.linspace(0.0, 1.0, 101, device=device)
+only = sys.argv[2] if len(sys.argv) > 2 else ""       # "bf16" / "f32": that engine only
+n_steps = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+t_span = torch.linspace(0.0, 1.0, n_steps + 1, device=device)
 for dtype, name in ((L.BF16, "bf16"), (L.F32, "f32")):
+    if only and name != only:
+        continue
     m5.model.compute_dtype = dtype
     m5.sample(t_span=t_span, x_0=x0)
     torch.cuda.synchronize()
@@ -29,4 +34,4 @@ for dtype, name in ((L.BF16, "bf16"), (L.F32, "f32")):
     m5.sample(t_span=t_span, x_0=x0)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print("C5 %s: %.3f s per call, %.3e action-steps/s, %.1f TFLOP/s" % (name, dt, rows * 100 / dt, rows * 100 * 6950912 / dt / 1e12))
+    print("C5 %s: %.3f s per call, %.3e action-steps/s, %.1f TFLOP/s" % (name, dt, rows * n_steps / dt, rows * n_steps * 6950912 / dt / 1e12))
