@@ -341,7 +341,8 @@ def test_bf16_wide_layers_256_tiles_match_the_128_tiles_bit_for_bit():
     """C5's [1024] net at 65 536 rows: its 1024-wide layers run k_bt_gemm_bf16_big (256 x 256 tiles, chosen when the
     grid fills the chip twice over); at 1 024 rows the same layers run the 128 x 128 kernel.  Same bf16 fragments, same
     k order, rows are independent: the first 1 024 rows of the big batch must equal the small batch BIT FOR BIT, and the
-    small batch is the one the oracle test above covers.  Also a ragged row count (65 536 + 300: the padded slab)."""
+    small batch is the one the oracle test above covers.  Also a ragged row count (65 536 + 300: slabs of more than
+    32 768 rows are padded to a multiple of 256, so this one runs the 256-tile kernel too)."""
     kind, cfg, m, sd = _bf16_model("gvp_wide")
     gen = torch.Generator().manual_seed(23)
     rows = 65536 + 300
@@ -355,6 +356,28 @@ def test_bf16_wide_layers_256_tiles_match_the_128_tiles_bit_for_bit():
     assert torch.equal(ragged[:65536], big)
     want = O.sample_forward_process(sd, cfg, kind, t_span, x_0=x0[65536 - 64:65536 + 64].cpu())[-1]
     close(ragged[65536 - 64:65536 + 64].cpu(), want, tol=BF16_TOL, what="bf16 256-tile kernel, rows around 65536")
+
+
+def test_bf16_256_tiles_on_a_three_level_net_without_a_fused_kernel():
+    """A [512,256,128] net with 20 action dimensions (no fused integrator: the batch engine in bf16) at 140 000 rows: its
+    512- and 256-wide layers (K = 128 ... 1024, dual products, U-Net concatenations) run the 256-tile kernel, the 128-wide
+    ones and the whole net at 1 000 rows the 128-tile kernel.  Rows are independent: bit-identical results."""
+    import generativerl_preview_amd as G
+    cfg = dict(gl.diffusion_cfg(20, gl.VP, "noise_function", [512, 256, 128], 17), device=DEV)
+    torch.manual_seed(20)
+    m = G.DiffusionModel(cfg).to(DEV)
+    m.model.compute_dtype = L.BF16
+    assert m.model.plan.fused_kernel() == ""
+    gen = torch.Generator().manual_seed(24)
+    rows = 140000
+    x0 = torch.randn(rows, 20, generator=gen).to(DEV)
+    cond = torch.randn(rows, 17, generator=gen).to(DEV)
+    t_span = torch.linspace(0.0, 1.0, 4)
+    big = m.sample(t_span=t_span, x_0=x0, condition=cond)
+    small = m.sample(t_span=t_span, x_0=x0[:1000].contiguous(), condition=cond[:1000].contiguous())
+    tail = m.sample(t_span=t_span, x_0=x0[-777:].contiguous(), condition=cond[-777:].contiguous())
+    assert torch.isfinite(big).all() and float(big.abs().max()) > 0
+    assert torch.equal(big[:1000], small) and torch.equal(big[-777:], tail)
 
 
 @pytest.mark.parametrize("x_dim,c_dim,guided", [(1, 5, False), (16, 32, True), (16, 33, False), (8, 16, True), (5, 67, False),
