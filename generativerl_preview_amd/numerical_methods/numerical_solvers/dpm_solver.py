@@ -2,9 +2,10 @@
 configurations ship with (order 2, 17 function evaluations).
 
 The per-step algebra is a handful of scalar schedule values (half-logSNR, log-scale, std) computed on the CPU in
-fp32 exactly as the reference computes them on tensors.  Orders 1-2, and order 3 with ``solver_type="dpm_solver"``,
-become a stage table that ONE ``grlhip_sample_stages`` call runs on the device (``_integrate_fused``); order 3
-"taylor" is stepped from the host, each model evaluation being the HIP forward (+ HIP energy gradient) of the C ABI.
+fp32 exactly as the reference computes them on tensors.  Orders 1-3 of both solver types become a stage table that
+ONE ``grlhip_sample_stages`` call runs on the device (``_integrate_fused``; the last stage of order 3 "taylor" uses
+the second saved model value, ``W2``).  With ``with_grad=True`` the same stages are stepped from the host with
+autograd on, each model evaluation being the differentiable HIP forward of the C ABI.
 Supported: ``method="singlestep"`` with orders 1-3, ``type`` "dpm_solver" / "dpm_solver++", ``solver_type``
 "dpm_solver" / "taylor", ``skip_type`` "time_uniform" / "time_quadratic".  The option values on which the
 reference itself fails raise here too (recorded in tests/golden/dpm.npz "raises"): ``skip_type="logSNR"``
