@@ -78,6 +78,26 @@ def test_energy_net_plan_has_training_programs():
     assert L.lib().grlhip_loss_workspace_bytes(plan.handle, 4096, L.F32) > 0
 
 
+def test_workspace_size_follows_the_slab_pitch():
+    """The slab's row pitch is rows rounded up to 128, and to 256 above 32 768 rows (so that the 256-tile bf16 GEMM covers
+    any large batch); batches beyond the chunk size are processed in chunks of 262 144 rows.  Seen from outside: the
+    workspace size is a step function of the row count with exactly those steps, and never decreases."""
+    from generativerl_preview_amd.engine import NetPlan
+    plan = NetPlan(L.NET_RESNET, 64, 64, 0, 32, 0, 0, [1024])
+    size = lambda rows: L.lib().grlhip_workspace_bytes(plan.handle, None, rows, L.BF16)  # noqa: E731
+    assert size(1) == size(128) < size(129) == size(256)
+    assert size(32768 - 127) == size(32768) < size(32769) == size(32768 + 256)
+    assert size(32768 + 257) == size(32768 + 512) > size(32768 + 256)
+    per_row = (size(32768 + 512) - size(32768 + 256)) // 256
+    assert per_row > 4 * 1024 and (size(256) - size(128)) == 128 * per_row     # bytes per slab row, same below the switch
+    assert size(262144) == size(10 ** 7)                                       # chunked beyond 262 144 rows
+    prev = 0
+    for rows in range(1, 70000, 97):
+        cur = size(rows)
+        assert cur >= prev
+        prev = cur
+
+
 def test_plan_rejects_bad_wiring():
     from generativerl_preview_amd.engine import NetPlan
     with pytest.raises(L.GrlHipError, match="hidden"):
