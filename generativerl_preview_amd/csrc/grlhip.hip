@@ -141,7 +141,7 @@ size_t grlhip_packed_bytes(const grlhip_plan* plan, int dtype) {
   if (!plan || !plan->p) return 0;
   if (dtype == GRLHIP_F32) return (size_t)plan->p->packed_floats * sizeof(float);
   // bf16 on a shape without a fused kernel runs the batch engine with bf16 MFMAs on the fp32 image
-  if (dtype == GRLHIP_BF16) return bf16_fused_ok(plan->p) ? bf16_packed_bytes(plan->p) : (size_t)plan->p->packed_floats * sizeof(float);
+  if (dtype == GRLHIP_BF16) return bf16_fused_ok(plan->p) ? bf16_packed_bytes(plan->p) : batch_bf16_packed_bytes(plan->p);
   return 0;
 }
 
@@ -180,6 +180,7 @@ int grlhip_pack_weights(const grlhip_plan* plan, const void* const* params, int 
   if (half)
     hipLaunchKernelGGL(k_copy_pad_f32, dim3(1), dim3(64), 0, st, (const float*)params[0], dst + p->fourier_off, half,
                        (int)(p->packed_floats - p->fourier_off));
+  if (dtype == GRLHIP_BF16) batch_mirror_weights(p, dst, st);   // (after the fp32 image on the same stream)
   HIP_TRY(hipGetLastError());
   return 0;
 }

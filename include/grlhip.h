@@ -98,7 +98,8 @@ int grlhip_plan_program_info(const grlhip_plan* plan, int program, int32_t* n_op
 int grlhip_bf16_fused_kernel(const grlhip_plan* plan, const grlhip_plan* guidance, char* name_buf, size_t name_buf_len);
 
 /* Bytes of the packed weight image for `dtype` (the image layout is private to the library and differs
- * per dtype and shape: always produce it with grlhip_pack_weights for the same plan and dtype). */
+ * per dtype and shape: always produce it with grlhip_pack_weights for the same plan and dtype; GRLHIP_BF16 of a
+ * network without a fused integrator is the fp32 image followed by a bf16 mirror of its matrices). */
 size_t grlhip_packed_bytes(const grlhip_plan* plan, int dtype);
 /* Derive the packed (padded / transposed / fragment-ordered) weight image from the reference-layout
  * parameters.  `params` is a HOST array of n DEVICE pointers (fp32), in grlhip_plan_param_info order. */
