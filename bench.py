@@ -42,17 +42,45 @@ def qgpo_config(device):
                                             condition_hidden_dim=32, t_condition_hidden_dim=128)))))
 
 
+TRAINED_WEIGHTS = os.path.join(ROOT, "tests", "golden", "weights_qgpo_noise.npz")
+
+
 def build_model(device):
+    """The C2 policy with the TRAINED weights the parity tests are asserted on (tests/golden/weights_qgpo_noise.npz:
+    the qgpo_noise golden model, a few hundred Adam steps of the reference's own loss, 100-step samples end at
+    |x| = O(1)); the file also holds the energy-guidance net, which this unguided config does not use."""
+    import numpy as np
     import generativerl_preview_amd as G
     from generativerl_preview_amd import _lib as L
-    torch.manual_seed(0)
     m = G.DiffusionModel(qgpo_config(device))
-    with torch.no_grad():  # keep sampled actions O(1) (last_block x 0.1)
-        m.model.model["backbone"].last_block.weight.mul_(0.1)
-        m.model.model["backbone"].last_block.bias.mul_(0.1)
+    z = np.load(TRAINED_WEIGHTS)
+    sd = {k: torch.from_numpy(np.ascontiguousarray(z[k], dtype=np.float32)) for k in z.files
+          if not k.startswith("energy_guidance.")}
+    m.load_state_dict(sd)     # strict: every key of the reference's state_dict layout must be there
     m = m.to(device)
     m.model.compute_dtype = L.BF16
     return m
+
+
+def check_against_oracle(model, states, out, seed, n_check=64, tol=2e-2):
+    """64 rows of the TIMED output against the CPU oracle (outside the timed region).  The last timed step drew its
+    x_T right after torch.manual_seed(seed): the same draw is repeated here.  Row r of the launch has x_T[r], the
+    condition states[r // K] (repeat_interleave) and lands in out.reshape(-1, D)[r] (diffusion_model.py:205-234, 369-416)."""
+    from oracle import grl_oracle as O
+    rows = states.shape[0] * N_CAND
+    torch.manual_seed(seed)
+    x_T = model.gaussian_generator(rows)
+    idx = torch.linspace(0, rows - 1, n_check, device=states.device).long()
+    x0, cond = x_T[idx].cpu(), states[idx // N_CAND].cpu()
+    got = out.reshape(-1, out.shape[-1])[idx].cpu()
+    del x_T
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    want = O.sample_forward_process(sd, qgpo_config("cpu"), "diffusion", torch.linspace(0.0, 1.0, N_SOLVER_STEPS + 1),
+                                    x_0=x0, condition=cond)[-1]
+    err = float((got - want).abs().max())
+    assert err <= tol, "timed output differs from the oracle: max-abs %.3e > %.1e" % (err, tol)
+    return {"rows_checked": n_check, "max_abs_err": err, "tolerance": tol, "max_abs_action": float(want.abs().max()),
+            "against": "oracle/grl_oracle.py (fp32 torch restatement of the reference), same x_T / states / grid"}
 
 
 def cpu_info():
@@ -139,8 +167,8 @@ def _time_gpu(fn, reps):
 
 def secondary_results(device, model):
     """Other BASELINE configs / engines on the same box, one object each (never the headline): the fp32 engine on the
-    C2 net (the precision trade), C5 (GVP [1024] D=64, 100-step ODE, batch 262144) and C3 (ICFM training step, batch
-    65536, fwd+bwd+Adam).  Small enough to add ~10 s to the run."""
+    C2 net (the precision trade) and C5 (GVP [1024] D=64, 100-step ODE, batch 262144).  Small enough to add ~10 s to
+    the run.  C3 (the training step) is c3_training(): it runs at every world size."""
     import generativerl_preview_amd as G
     from generativerl_preview_amd import _lib as L
     res = []
@@ -179,33 +207,66 @@ def secondary_results(device, model):
         del m5, x0
     except Exception as e:  # noqa: BLE001
         res.append({"name": "C5_gvp_wide", "error": repr(e)})
-    try:   # C3: ICFM training step
-        cfg = dict(device=device, x_size=6, alpha=1.0, path=dict(sigma=0.1),
-                   solver=dict(type="ODESolver", args=dict(library="torchdyn")),
-                   model=qgpo_config(device)["model"])
-        cfg["model"] = dict(cfg["model"], type="velocity_function")
-        torch.manual_seed(0)
-        m3 = G.IndependentConditionalFlowModel(cfg).to(device)
-        from generativerl_preview_amd.distributed import attach_flat_grads
-        fg = attach_flat_grads(m3.model)   # every .grad is a view of ONE flat buffer: one zero, one all-reduce when N>1
-        opt = torch.optim.Adam(m3.parameters(), lr=1e-4)
-        B = 65536
-        x1 = torch.rand(B, 6, device=device, generator=gen) * 2 - 1
-        cond = torch.randn(B, 17, device=device, generator=gen)
+    return res
 
-        def train_step():
-            fg.zero()
+
+def c3_training(ranks, dry=False, steps=20, warmup=5):
+    """BASELINE config C3 on every rank of this launch: GMPO ICFM flow_matching_loss fwd + bwd into ONE flat fp32
+    gradient buffer, ONE in-place all-reduce of that buffer (RCCL through torch.distributed at world > 1, weighted by
+    rows; nothing at world 1), Adam.  65 536 rows per GPU (weak scaling), barrier + synchronize on both sides, MAX over
+    ranks.  Returns the `secondary` entry on rank 0.  dry: gloo on CPU, the fused loss replaced by a stub that writes
+    rank-dependent gradients into the same FlatGrads buffer, so the all-reduce and its row weighting are exercised."""
+    import generativerl_preview_amd as G
+    from generativerl_preview_amd.distributed import attach_flat_grads
+    rank, world, device = ranks.rank, ranks.world, ranks.device
+    hidden = [64, 32, 16] if dry else [512, 256, 128]
+    model_cfg = qgpo_config(device)["model"]
+    model_cfg = dict(model_cfg, type="velocity_function")
+    model_cfg["args"]["backbone"]["args"]["hidden_sizes"] = hidden
+    cfg = dict(device=device, x_size=6, alpha=1.0, path=dict(sigma=0.1),
+               solver=dict(type="ODESolver", args=dict(library="torchdyn")), model=model_cfg)
+    torch.manual_seed(0)    # identical initial weights on every rank
+    m3 = G.IndependentConditionalFlowModel(cfg).to(device)
+    fg = attach_flat_grads(m3.model)   # every .grad is a view of ONE flat buffer: one zero, one all-reduce
+    opt = torch.optim.Adam(m3.parameters(), lr=1e-4)
+    B = (8 + 5 * rank) if dry else 65536
+    gen = torch.Generator(device=device).manual_seed(11 + rank)
+    x1 = torch.rand(B, 6, device=device, generator=gen) * 2 - 1
+    cond = torch.randn(B, 17, device=device, generator=gen)
+    check = {}
+
+    def train_step():
+        fg.zero()
+        if dry:
+            fg.grads.fill_(float(rank + 1))
+            loss = torch.tensor(float(rank + 1))
+        else:
             loss = m3.flow_matching_loss(torch.randn(B, 6, device=device, generator=gen), x1, cond)
-            loss.backward()
-            opt.step()
-            return loss
-        for _ in range(5):
-            train_step()
-        dt, loss = _time_gpu(train_step, 20)
-        tf = B * 9759936 / dt / 1e12
-        entry = {"name": "C3_icfm_train", "workload": "C3 GMPO ICFM flow_matching_loss fwd+bwd+Adam, batch %d, 1 GPU" % B,
-                 "dtype": "f32", "value": B / dt, "unit": "rows/s", "ms_per_step": dt * 1e3, "final_loss": float(loss.detach()),
-                 "roofline": f32_roofline(tf)}
+            loss.backward()                  # one fused pass into the flat buffer
+        gloss = fg.allreduce(B, loss)        # ONE in-place all-reduce (returns the local loss at world 1)
+        if dry:
+            check["grad"], check["loss"] = float(fg.grads[0]), float(gloss)
+        opt.step()
+        return gloss
+
+    elapsed, loss = ranks.timed(train_step, warmup, steps)
+    assert bool(torch.isfinite(loss))
+    if rank != 0:
+        return None
+    dt = elapsed / steps
+    entry = {"name": "C3_icfm_train",
+             "workload": "C3 GMPO ICFM flow_matching_loss fwd+bwd + flat-gradient all-reduce + Adam, batch %d per GPU, %d GPU(s)" % (B, world),
+             "dtype": "f32", "value": B * world / dt, "unit": "rows/s", "ms_per_step": dt * 1e3, "n_gpus": world,
+             "scaling": "weak", "final_loss": float(loss.detach()),
+             "allreduce": {"world_size": world, "backend": ranks.backend, "elements": int(fg.flat.numel()),
+                           "collectives_per_step": 1 if world > 1 else 0}}
+    if dry:
+        rows = [8 + 5 * r for r in range(world)]
+        entry["allreduce_check"] = {"got_grad": check["grad"], "got_loss": check["loss"],
+                                    "expected": sum(n * (r + 1.0) for r, n in enumerate(rows)) / sum(rows)}
+        return entry
+    entry["roofline"] = f32_roofline(B * 9759936 / dt / 1e12)   # per GPU, whole step over wall time
+    if world == 1:
         try:   # the same step on the host cores through the oracle (bounded sample)
             from oracle import grl_oracle as O
             torch.set_num_threads(cpu_threads())
@@ -229,10 +290,7 @@ def secondary_results(device, model):
                                      "sample": "%d steps of batch %d, oracle loss + torch autograd + Adam, %.1f s" % (n, Bc, cdt * n)}
         except Exception as e:  # noqa: BLE001
             entry["cpu_baseline"] = {"error": repr(e)}
-        res.append(entry)
-    except Exception as e:  # noqa: BLE001
-        res.append({"name": "C3_icfm_train", "error": repr(e)})
-    return res
+    return entry
 
 
 def main():
@@ -289,14 +347,25 @@ def main():
             events.append(ev)
             return r
         engine.NetPlan.sample = timed_sample
+    check_seed = 4242 + rank
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if i == args.steps - 1:
+            torch.manual_seed(check_seed)   # the last step's x_T draw is repeated by check_against_oracle()
         out = step()
     ranks.barrier()
     elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
     if engine is not None:
         engine.NetPlan.sample = plan_sample
     assert out.shape == (N_CAND, args.states, 6) and bool(torch.isfinite(out).all())
+
+    parity = None
+    if engine is not None and rank == 0:
+        parity = check_against_oracle(model, states, out, check_seed)   # asserts 2e-2; outside the timed region
+    del out
+    # C3 on every rank (the one gradient all-reduce per step is the only collective of the whole path)
+    c3 = None if args.no_secondary else c3_training(ranks, dry=args.dry, steps=3 if args.dry else 20,
+                                                    warmup=1 if args.dry else 5)
 
     if rank == 0:
         total_rows = rows * world * args.steps
@@ -306,14 +375,18 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "action_steps_per_s": total_rows * N_SOLVER_STEPS / elapsed,
+            "backend": ranks.backend, "rccl_world_size": ranks.collective_world,
             "config": {"workload": "C2 QGPO HalfCheetah-shaped sampling: %d states x %d candidates per GPU, "
                                    "100-step Euler ODE on linspace(0,1,101), linear VP-SDE noise net [512,256,128], "
                                    "obs 17 / act 6, unguided, finals only" % (args.states, N_CAND),
+                       "weights": "trained (tests/golden/weights_qgpo_noise.npz), synthetic states",
                        "rows_per_gpu": rows, "solver_steps": N_SOLVER_STEPS, "parallelism": "batch-sharded x%d, no collective" % world},
         }
         if args.dry:
             res["dry"] = True
             res["roofline"] = None
+            if c3 is not None:
+                res["secondary"] = [c3]
         else:
             kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, len(events))
             achieved = rows * N_SOLVER_STEPS * FLOP_PER_ACTION_STEP / (kernel_ms * 1e-3) / 1e12
@@ -323,11 +396,16 @@ def main():
                                "traffic_source": traffic_src,
                                "kernel": "k_sample_bf16", "kernel_ms": kernel_ms,
                                "algorithmic_flop_per_launch": rows * N_SOLVER_STEPS * FLOP_PER_ACTION_STEP}
+            res["parity"] = parity
             if world == 1 and not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(model)
+            sec = []
             if world == 1 and not args.no_secondary:
-                del out
-                res["secondary"] = secondary_results(device, model)
+                sec = secondary_results(device, model)
+            if c3 is not None:
+                sec.append(c3)
+            if sec:
+                res["secondary"] = sec
         print(json.dumps(res), flush=True)
     ranks.close()
 

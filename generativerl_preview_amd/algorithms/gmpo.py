@@ -118,16 +118,16 @@ class GMPOPolicy(nn.Module):
     def policy_optimization_loss_by_advantage_weighted_regression_softmax(self, state, fake_action,
                                                                           maximum_likelihood: bool = False,
                                                                           beta: float = 1.0):
-        """:340-405, as written (the final ``torch.mean(..., dim=1)`` over a 1-D tensor raises in torch, here as there)"""
-        action = fake_action
-        action_reshape = action.reshape(action.shape[0] * action.shape[1], *action.shape[2:])
-        state_repeat = torch.stack([state] * action.shape[1], axis=1)
-        state_repeat_reshape = state_repeat.reshape(state_repeat.shape[0] * state_repeat.shape[1], *state_repeat.shape[2:])
+        """Softmax-weighted regression over each state's K support actions (reference :340-405).  Every (state,
+        candidate) pair is one row of the fused per-row loss; the critic's Q over the same rows, soft-maxed per state
+        at temperature 1 / beta, gives the weights.  The reference finishes with ``torch.mean(..., dim=1)`` of a 1-D
+        tensor, which raises IndexError in torch; that call is kept so the failure is the same."""
+        n_states, n_cand = fake_action.shape[0], fake_action.shape[1]
+        rows_a = fake_action.flatten(0, 1)
+        rows_s = state.unsqueeze(1).expand(n_states, n_cand, *state.shape[1:]).flatten(0, 1)
         with torch.no_grad():
-            energy = self.critic(action_reshape, state_repeat_reshape).detach()
-        energy = energy.reshape(action.shape[0], action.shape[1]).squeeze(dim=-1)
-        model_loss = self._model_loss(self.guided_model, action_reshape, state_repeat_reshape, maximum_likelihood, False)
-        model_loss = model_loss.reshape(action.shape[0], action.shape[1]).squeeze(dim=-1)
-        relative_energy = nn.Softmax(dim=1)(energy * beta)
-        loss = torch.mean(torch.sum(relative_energy * model_loss, axis=-1), dim=1)
-        return loss, torch.mean(energy), torch.mean(relative_energy), torch.mean(model_loss)
+            q = self.critic(rows_a, rows_s).view(n_states, n_cand)
+        per_row = self._model_loss(self.guided_model, rows_a, rows_s, maximum_likelihood, False).view(n_states, n_cand)
+        w = torch.softmax(beta * q, dim=1)
+        loss = torch.mean((w * per_row).sum(dim=-1), dim=1)
+        return loss, q.mean(), w.mean(), per_row.mean()

@@ -8,6 +8,12 @@
 #include "engine_bf16.hip.inc"
 #include "engine_bf16_variants.hpp"
 
+// the product library carries the shipped schedule only: a body generated under GEN_* experiment knobs (some of which
+// give wrong results by design) compiles only in an experiment build (csrc/xbuild.sh passes -DB16_EXPERIMENT)
+#if !defined(B16_EXPERIMENT)
+static_assert(B16_GEN_DEFAULT_KNOBS == 1, "engine_bf16_body_gen.inc was generated with non-default GEN_* knobs");
+#endif
+
 namespace grlhip {
 #if B16_VARIANT == 0
 using CfgSel = CfgQgpo;

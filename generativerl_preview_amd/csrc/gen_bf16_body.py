@@ -31,7 +31,14 @@ element, same KD-scaled activation domain)."""
 import os
 import sys
 
-# ---- knobs (environment): the defaults are the shipped schedule; GEN_X are timing experiments with WRONG results
+# ---- knobs (environment): the defaults are the shipped schedule; GEN_X are timing experiments with WRONG results.
+# A stray GEN_* variable in the build shell must not ship a different kernel: any of them set without
+# GEN_EXPERIMENT=1 is refused, and the knob values are written into the generated header (B16_GEN_DEFAULT_KNOBS),
+# where engine_bf16_inst.hip static_asserts the shipped schedule unless it is itself built with -DB16_EXPERIMENT.
+_KNOB_VARS = sorted(k for k in os.environ if k.startswith("GEN_") and k != "GEN_EXPERIMENT")
+if _KNOB_VARS and os.environ.get("GEN_EXPERIMENT") != "1":
+    sys.exit("gen_bf16_body.py: %s set in the environment; experiment builds need GEN_EXPERIMENT=1 "
+             "(they never go into libgrlhip.so)" % ", ".join(_KNOB_VARS))
 DBG_LO = int(os.environ.get("GEN_LO", "2"))
 DBG_NOP = int(os.environ.get("GEN_NOP", "0"))
 X = set(filter(None, os.environ.get("GEN_X", "").split(",")))   # novalu, nodma, nobarrier, nofrag, nowait, nowaitv
@@ -742,7 +749,12 @@ CONFIGS = [
 
 if __name__ == "__main__":
     out = sys.argv[1]
+    knobs = dict(LO=DBG_LO, NOP=DBG_NOP, X=",".join(sorted(X)), SPREAD=SPREAD, WAITB=WAITB, BSPREAD=BSPREAD, SKEW=SKEW,
+                 PF=QSLOTS, NSLOT=CONFIGS[0].nslot, CF=CONFIGS[0].cf)
+    shipped = dict(LO=2, NOP=0, X="", SPREAD=-1, WAITB=4, BSPREAD=2, SKEW=0, PF=8, NSLOT=4, CF=16)
     parts = ["// GENERATED by gen_bf16_body.py -- do not edit.  See that file for the design.", "#pragma once",
+             "// generator knobs: " + " ".join("%s=%s" % kv for kv in sorted(knobs.items())),
+             "#define B16_GEN_DEFAULT_KNOBS %d" % int(knobs == shipped),
              "namespace grlhip {", "namespace b16 {", "typedef int i32x4 __attribute__((ext_vector_type(4)));"]
     for cfg in CONFIGS:
         text, cnt, n, b = function_text(cfg)

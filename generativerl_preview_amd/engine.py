@@ -105,9 +105,11 @@ class NetPlan:
         return ws
 
     def train_workspace(self, rows, device):
-        """Cached workspace of the training / backward entry points (gigabytes at 65 536 rows): grown on demand."""
+        """Cached workspace of the training / backward entry points (gigabytes at 65 536 rows): grown on demand.
+        One per (device, current stream): the dW partials that make the gradients bit-reproducible live in it, so two
+        calls of one plan issued on different streams must not share a slab."""
         need = L.lib().grlhip_loss_workspace_bytes(self.handle, rows, L.F32)
-        key = (str(device), "train")
+        key = (str(device), "train", int(torch.cuda.current_stream(device).cuda_stream))
         ws = self._ws.get(key)
         if ws is None or ws.numel() < need:
             self._ws.pop(key, None)

@@ -116,7 +116,7 @@ def _param_grads(model, flat, n_params):
 
 class _StageToken:
     """Lives as long as the autograd node whose backward still needs the staged gradient."""
-    __slots__ = ("__weakref__",)
+    __slots__ = ("__weakref__", "gen")
 
 
 def _stage(model, n, dev):
@@ -134,7 +134,25 @@ def _stage(model, n, dev):
     st.zero_()
     token = _StageToken()
     model._stage_token = weakref.ref(token)
+    model._stage_gen = getattr(model, "_stage_gen", 0) + 1
+    token.gen = model._stage_gen
     return st, token
+
+
+def _consume(ctx):
+    """Backward has read the staged gradient: give the cached buffer back (in the usual loop the loss tensor of
+    step i is still bound while step i + 1 runs its forward, which would otherwise get a fresh buffer every second
+    step).  A second backward through the same node (retain_graph=True) is still fine as long as no other loss of
+    this model ran in between; after one did, the buffer holds that call's gradient and this raises."""
+    token = ctx.token
+    if token is None:
+        if getattr(ctx, "stage_gen", None) is not None and ctx.flat is getattr(ctx.model, "_grad_stage", None) \
+                and ctx.stage_gen != getattr(ctx.model, "_stage_gen", None):
+            raise RuntimeError("fused loss: backward called again (retain_graph) after another loss of the same model "
+                               "reused the staged gradient buffer; not supported")
+        return
+    ctx.stage_gen = token.gen
+    ctx.token = None
 
 
 class _FusedLoss(torch.autograd.Function):
@@ -171,6 +189,7 @@ class _FusedLoss(torch.autograd.Function):
         if ctx.average:
             flat = ctx.flat
             scale = gout
+            _consume(ctx)
         else:
             t, x_t, cond, alpha, beta, target = ctx.saved_tensors
             flat = torch.zeros(L.lib().grlhip_grad_numel(plan.handle), dtype=torch.float32, device=x_t.device)
@@ -239,6 +258,7 @@ class _FusedCepLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         model, flat = ctx.model, ctx.flat
+        _consume(ctx)
         fg = getattr(model, "_flat_grads", None)
         if fg is not None and flat is not None:
             fg.ensure()

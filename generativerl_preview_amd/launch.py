@@ -36,6 +36,8 @@ def self_launch(gpus: int, argv=None, timeout=None) -> int:
     for rank in range(gpus):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(gpus),
                    LOCAL_WORLD_SIZE=str(gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # the host driver of these machines supports dmabuf IPC only: without this RCCL's intra-node buffer exchange
+        # fails with `hipIpcGetMemHandle: invalid argument`.  The image exports it already; kept for bare environments.
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # ranks other than 0 keep stderr (diagnostics) but must not add lines to stdout
         procs.append(subprocess.Popen([sys.executable] + argv, env=env,
@@ -80,6 +82,8 @@ class Ranks:
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
         self.dry = dry
         self.dist = None
+        self.backend = None          # "nccl" (= RCCL on ROCm) / "gloo" once a process group exists
+        self.collective_world = 1    # world size the collective backend itself reports
         if self.world != gpus:
             raise SystemExit("--gpus %d does not match WORLD_SIZE=%d of the launcher" % (gpus, self.world))
         if dry:
@@ -97,6 +101,8 @@ class Ranks:
                                         device_id=torch.device("cuda", self.local))
             self.dist = dist
             self.world = dist.get_world_size()   # what the backend observed
+            self.collective_world = self.world
+            self.backend = dist.get_backend()
 
     def sync(self):
         import torch

@@ -156,6 +156,16 @@ def test_bench_launches_its_own_ranks():
     assert res["n_gpus"] == 2 and res["steps"] == 3 and res["warmup"] == 1 and res["dry"] is True
     assert res["ms_per_step"] >= 10.0          # MAX over ranks: rank 1's stub sleeps 10 ms per step, rank 0's 5 ms
     assert abs(res["value"] - 16 * 32 * 2 * 3 / (res["ms_per_step"] * 3e-3)) < 1e-6 * res["value"]
+    # what the collective backend itself observed, and the C3 training leg: every rank runs the step and its ONE
+    # all-reduce of the flat gradient buffer, weighted by rows (ranks hold 8 and 13 rows, stub gradients 1 and 2)
+    assert res["backend"] == "gloo" and res["rccl_world_size"] == 2
+    c3 = [e for e in res["secondary"] if e["name"] == "C3_icfm_train"]
+    assert len(c3) == 1 and c3[0]["n_gpus"] == 2
+    assert c3[0]["allreduce"] == {"world_size": 2, "backend": "gloo", "elements": c3[0]["allreduce"]["elements"],
+                                  "collectives_per_step": 1}
+    chk = c3[0]["allreduce_check"]
+    assert abs(chk["expected"] - (8 * 1.0 + 13 * 2.0) / 21) < 1e-12
+    assert abs(chk["got_grad"] - chk["expected"]) < 1e-6 and abs(chk["got_loss"] - chk["expected"]) < 1e-6
     # a mismatching launcher world size is refused, not silently run
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry", "--states", "16"],
                          env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)

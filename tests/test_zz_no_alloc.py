@@ -47,11 +47,19 @@ def _both(m, g, rows, n_steps, seed):
         L.check(lib.grlhip_sample_ode(plan.handle, _ptr(packed), L.BF16, g_h, _ptr(g_packed), _ptr(x0), _ptr(cond),
                                       _ptr(coef), n_steps, rows, _ptr(want), None, _ptr(ws), ws.numel(), _stream(DEV)))
         torch.cuda.synchronize()
-        before = torch.cuda.memory_allocated(DEV)
-        L.check(lib.grlhip_sample_ode_static(plan.handle, _ptr(packed), g_h, _ptr(g_packed), _ptr(x0), _ptr(cond),
-                                             _ptr(coef), n_steps, rows, _ptr(got), None, _stream(DEV)))
+        def static_call():
+            L.check(lib.grlhip_sample_ode_static(plan.handle, _ptr(packed), g_h, _ptr(g_packed), _ptr(x0), _ptr(cond),
+                                                 _ptr(coef), n_steps, rows, _ptr(got), None, _stream(DEV)))
+            torch.cuda.synchronize()
+        static_call()    # the first call on a device resolves the scratch symbol (may load the code object)
+        got.fill_(float("nan"))
         torch.cuda.synchronize()
+        # torch's counter only sees torch's caching allocator; the driver's free-byte count (hipMemGetInfo) also
+        # sees a hipMalloc / hipFree made inside the library
+        before, free_before = torch.cuda.memory_allocated(DEV), torch.cuda.mem_get_info(DEV)[0]
+        static_call()
         assert torch.cuda.memory_allocated(DEV) == before
+        assert torch.cuda.mem_get_info(DEV)[0] == free_before
     assert bool(torch.isfinite(want).all())
     assert torch.equal(got, want), float((got - want).abs().max())
 
