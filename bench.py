@@ -70,7 +70,8 @@ def check_against_oracle(model, states, out, seed, n_check=64, tol=2e-2):
     rows = states.shape[0] * N_CAND
     torch.manual_seed(seed)
     x_T = model.gaussian_generator(rows)
-    idx = torch.linspace(0, rows - 1, n_check, device=states.device).long()
+    idx = torch.arange(n_check, device=states.device, dtype=torch.int64) * ((rows - 1) // max(1, n_check - 1))  # first .. last row
+    assert int(idx.max()) < rows
     x0, cond = x_T[idx].cpu(), states[idx // N_CAND].cpu()
     got = out.reshape(-1, out.shape[-1])[idx].cpu()
     del x_T

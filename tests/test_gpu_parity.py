@@ -244,14 +244,14 @@ def test_bf16_trajectory_and_sde_vs_golden():
         if not use_x0:
             um.fix_noise(m, cu(s["xT_T%d_b%s_x0" % (Tn, bs)]))
         traj = m.sample_forward_process(**kw)
-        close(traj, s[key], tol=BF16_TOL, what="bf16 swiss trajectory " + key, rel=True)
+        close(traj, s[key], tol=BF16_TOL, what="bf16 swiss trajectory " + key)
         close(traj[-1], s[key][-1], tol=BF16_TOL, what="bf16 swiss final " + key)
     for Tn, dt in ((11, 0.1), (21, 0.05)):
         um.fix_noise(m, cu(s["sde_T%d_xT" % Tn]))
         out = m.sample_forward_process(t_span=torch.linspace(0.0, 1.0, Tn), batch_size=2,
                                        solver_config=dict(type="SDESolver", args=dict(library="torchsde", dt=dt)),
                                        noise_increments=cu(s["sde_T%d_dW" % Tn]))
-        close(out, s["sde_T%d" % Tn], tol=BF16_TOL, what="bf16 swiss sde trajectory T%d" % Tn, rel=True)
+        close(out, s["sde_T%d" % Tn], tol=BF16_TOL, what="bf16 swiss sde trajectory T%d" % Tn)
         close(out[-1], s["sde_T%d" % Tn][-1], tol=BF16_TOL, what="bf16 swiss sde final T%d" % Tn)
 
 
@@ -272,7 +272,7 @@ def test_bf16_guided_sampling_vs_golden():
                   condition=cu(s["cond"]), guidance_scale=gs)
         if not use_x0:
             um.fix_noise(m, cu(s["xT_T%d_b%s_x0" % (Tn, bs)]))
-        close(m.sample_forward_process(**kw), s[key], tol=BF16_TOL, what="bf16 guided trajectory " + key, rel=True)
+        close(m.sample_forward_process(**kw), s[key], tol=BF16_TOL, what="bf16 guided trajectory " + key)
         close(m.sample(**kw), s[key][-1], tol=BF16_TOL, what="bf16 guided final " + key)
         n += 1
     assert n >= 8
@@ -283,7 +283,7 @@ def test_bf16_guided_sampling_vs_golden():
                                            guidance_scale=float(gs),
                                            solver_config=dict(type="SDESolver", args=dict(library="torchsde", dt=dt)),
                                            noise_increments=cu(s["sde_T%d_dW" % Tn]))
-            close(out, s["sde_T%d_g%d" % (Tn, gs)], tol=BF16_TOL, what="bf16 guided sde trajectory T%d g%d" % (Tn, gs), rel=True)
+            close(out, s["sde_T%d_g%d" % (Tn, gs)], tol=BF16_TOL, what="bf16 guided sde trajectory T%d g%d" % (Tn, gs))
             close(out[-1], s["sde_T%d_g%d" % (Tn, gs)][-1], tol=BF16_TOL, what="bf16 guided sde final T%d g%d" % (Tn, gs))
 
 
