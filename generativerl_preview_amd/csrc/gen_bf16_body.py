@@ -46,6 +46,9 @@ SPREAD = int(os.environ.get("GEN_SPREAD", "-1"))  # > 0: one LDS-DMA piece every
 WAITB = int(os.environ.get("GEN_WAITB", "4"))    # one s_waitcnt per WAITB weight fragments
 BSPREAD = int(os.environ.get("GEN_BSPREAD", "2"))  # > 0: bias ds_reads spread, BSPREAD per gap
 SKEW = int(os.environ.get("GEN_SKEW", "0"))      # > 0: after every ring hand-off wave w idles w * SKEW wait states
+DPOS = int(os.environ.get("GEN_DPOS", "0"))      # where in an MFMA gap an LDS-DMA piece goes: 0 after the gap's fragment read, 1 at the end of the gap (after its VALU work), 2 right after the MFMA
+DMAPOL = os.environ.get("GEN_DMAPOL", "")         # cache-policy bits on the LDS-DMA loads of the weight stream: "", "nt", "sc1", "sc0 sc1" ...
+ROT = int(os.environ.get("GEN_ROT", "0"))        # 1: one body per wave; wave w issues its LDS-DMA pieces in the gaps = w (mod 4) of each chunk, so that no two waves of the CU issue a piece in the same MFMA gap
 ACC = (0, 32)       # two accumulator buffers of 32 registers
 HB = 64             # 32 fragments x 4
 QBASE = 192
@@ -298,8 +301,9 @@ def guide_epilogue_3(pa, d1, out):
 
 
 class Body:
-    def __init__(self, cfg):
+    def __init__(self, cfg, rot=None):
         self.c = cfg
+        self.rot = rot      # wave id this body is for (ROT), or None: one body for all waves
         self.mf = []        # MFMA list: dict(D, B, chain-first flag, bias seqs to wait for, tile)
         self.tiles = []     # dict(first, last, buf, ops (epilogue), outputs (register names), kind)
         self.out = []
@@ -497,7 +501,11 @@ class Body:
             assert not getattr(self, "dma_pending", []), "previous chunk's pieces not issued yet"
             self.dma_pending = [p for p in range(loads)]
             self.dma_count = 0
-            if SPREAD < 0:
+            if self.rot is not None:
+                # one piece per MFMA gap and CU: this wave's are the gaps = rot (mod 4) counted from the hand-off
+                g0 = self.cur_gap + 1
+                self.dma_gaps = set(g0 + self.rot + (c.cf // loads) * i for i in range(loads))
+            elif SPREAD < 0:
                 # slack-aware: the `loads` cheapest of the next gaps (by the issue cost of what is already placed
                 # there), leaving the last two gaps before the next hand-off alone
                 g0 = self.cur_gap
@@ -517,7 +525,7 @@ class Body:
             self.emit("s_add_u32 m0, m0, 0x1000")
             self.emit("s_nop 0")
         off = " offset:%d" % ((p % 4) * 1024) if p % 4 else ""
-        self.emit("buffer_load_dwordx4 %%[voff], %%[rsrc], %%[soff] offen%s lds" % off)
+        self.emit("buffer_load_dwordx4 %%[voff], %%[rsrc], %%[soff] offen%s%s lds" % (off, (" " + DMAPOL) if DMAPOL else ""))
 
     def dma_tick(self, flush=False):
         if not SPREAD:
@@ -668,15 +676,20 @@ class Body:
                 for i, slot in enumerate(park):
                     self.emit("ds_read_b128 %s, %%[park] offset:%d" % (aq(A_STE + 4 * i), slot * 1024))
                     group_seq["in1"] = self.lds_issue()
+            if DPOS == 2 and not (g + PF < nf and (g + PF) % c.cf == 0):
+                self.dma_tick()
             if g + PF < nf:
                 if (g + PF) % c.cf == 0:
                     self.dma_tick(flush=True)     # pieces of the previous chunk must be issued before the next hand-off
                 self.frag_read(g + PF)
-            self.dma_tick()
+            if DPOS == 0 or (DPOS == 2 and g + PF < nf and (g + PF) % c.cf == 0):
+                self.dma_tick()
             bias_reads(g)
             for op in valu_at.get(g, []):
                 if "novalu" not in X:
                     self.emit(op.text)
+            if DPOS == 1:
+                self.dma_tick()
         # epilogue ops scheduled past the last MFMA (none expected) and the padding chunks of the ring
         for g in sorted(k for k in valu_at if k >= nf):
             for op in valu_at[g]:
@@ -702,8 +715,9 @@ def in_frags_base(name):
 
 
 def function_text(cfg):
-    b = Body(cfg)
-    lines = b.generate()
+    bodies = [Body(cfg, r) for r in range(4)] if ROT else [Body(cfg)]
+    all_lines = [b.generate() for b in bodies]
+    b, lines = bodies[0], all_lines[0]
     cnt = {}
     for l in lines:
         k = l.split()[0]
@@ -723,17 +737,22 @@ def function_text(cfg):
     o.append("  static __device__ __forceinline__ void run(uint32_t park, uint32_t voff, uint32_t rd, uint32_t bias, "
              "i32x4 rsrc, uint32_t ldsw, uint32_t wid, float* o) {")
     o.append("    uint32_t soff;")
-    o.append("    asm volatile(")
-    for l in lines:
-        o.append('      "%s\\n\\t"' % l)
     outs = ", ".join('[o%d] "=v"(o[%d])' % (i, i) for i in range(16 if cfg.guide else 8)) + ', [soff] "=&s"(soff)'
     ins = '[park] "v"(park), [voff] "v"(voff), [rd] "v"(rd), [bias] "v"(bias), [rsrc] "s"(rsrc), [ldsw] "s"(ldsw), [wid] "s"(wid)'
     clob = ['"memory"', '"scc"']
     clob += ['"v%d"' % i for i in range(NV)]
     clob += ['"a%d"' % i for i in range(256)]
-    o.append("      : %s" % outs)
-    o.append("      : %s" % ins)
-    o.append("      : %s);" % ", ".join(clob))
+    for r, blines in enumerate(all_lines):
+        if len(all_lines) > 1:   # one body per wave of the workgroup (wid is wave-uniform)
+            o.append("    %sif (wid == %d) {" % ("" if r == 0 else "else ", r) if r < len(all_lines) - 1 else "    else {")
+        o.append("    asm volatile(")
+        for l in blines:
+            o.append('      "%s\\n\\t"' % l)
+        o.append("      : %s" % outs)
+        o.append("      : %s" % ins)
+        o.append("      : %s);" % ", ".join(clob))
+        if len(all_lines) > 1:
+            o.append("    }")
     o.append("  }")
     o.append("};")
     return "\n".join(o), cnt, len(lines), b
@@ -750,8 +769,8 @@ CONFIGS = [
 if __name__ == "__main__":
     out = sys.argv[1]
     knobs = dict(LO=DBG_LO, NOP=DBG_NOP, X=",".join(sorted(X)), SPREAD=SPREAD, WAITB=WAITB, BSPREAD=BSPREAD, SKEW=SKEW,
-                 PF=QSLOTS, NSLOT=CONFIGS[0].nslot, CF=CONFIGS[0].cf)
-    shipped = dict(LO=2, NOP=0, X="", SPREAD=-1, WAITB=4, BSPREAD=2, SKEW=0, PF=8, NSLOT=4, CF=16)
+                 PF=QSLOTS, NSLOT=CONFIGS[0].nslot, CF=CONFIGS[0].cf, ROT=ROT, DPOS=DPOS, DMAPOL=DMAPOL)
+    shipped = dict(LO=2, NOP=0, X="", SPREAD=-1, WAITB=4, BSPREAD=2, SKEW=0, PF=8, NSLOT=4, CF=16, ROT=0, DPOS=0, DMAPOL="")
     parts = ["// GENERATED by gen_bf16_body.py -- do not edit.  See that file for the design.", "#pragma once",
              "// generator knobs: " + " ".join("%s=%s" % kv for kv in sorted(knobs.items())),
              "#define B16_GEN_DEFAULT_KNOBS %d" % int(knobs == shipped),
