@@ -25,6 +25,7 @@ int device_cus() {  // CU count of the CURRENT device (cached per device ordinal
 
 #include "pack_f32.hip.inc"
 #include "engine_batch.hip.inc"
+#include "engine_wide.hip.inc"
 #include "engine_bf16_host.hip.inc"
 
 struct grlhip_plan {
@@ -141,7 +142,8 @@ size_t grlhip_packed_bytes(const grlhip_plan* plan, int dtype) {
   if (!plan || !plan->p) return 0;
   if (dtype == GRLHIP_F32) return (size_t)plan->p->packed_floats * sizeof(float);
   // bf16 on a shape without a fused kernel runs the batch engine with bf16 MFMAs on the fp32 image
-  if (dtype == GRLHIP_BF16) return bf16_fused_ok(plan->p) ? bf16_packed_bytes(plan->p) : batch_bf16_packed_bytes(plan->p);
+  if (dtype == GRLHIP_BF16)
+    return bf16_fused_ok(plan->p) ? bf16_packed_bytes(plan->p) : wide_ok(plan->p) ? wide_packed_bytes(plan->p) : batch_bf16_packed_bytes(plan->p);
   return 0;
 }
 
@@ -181,6 +183,7 @@ int grlhip_pack_weights(const grlhip_plan* plan, const void* const* params, int 
     hipLaunchKernelGGL(k_copy_pad_f32, dim3(1), dim3(64), 0, st, (const float*)params[0], dst + p->fourier_off, half,
                        (int)(p->packed_floats - p->fourier_off));
   if (dtype == GRLHIP_BF16) batch_mirror_weights(p, dst, st);   // (after the fp32 image on the same stream)
+  if (dtype == GRLHIP_BF16 && wide_ok(p)) wide_pack(p, dst, st);   // row-major bf16 engine of the wide nets (engine_wide.hip.inc)
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -189,7 +192,8 @@ size_t grlhip_workspace_bytes(const grlhip_plan* plan, const grlhip_plan* guidan
   if (!plan || !plan->p || rows <= 0) return 0;
   if (dtype == GRLHIP_BF16) {
     if (bf16_fused_ok(plan->p)) return bf16_workspace_bytes(plan->p, guidance ? guidance->p : nullptr, rows);
-    return batch_workspace_bytes(plan->p, guidance ? guidance->p : nullptr, rows);
+    const size_t need = batch_workspace_bytes(plan->p, guidance ? guidance->p : nullptr, rows);
+    return wide_ok(plan->p) ? std::max(need, wide_workspace_bytes(plan->p, rows)) : need;
   }
   return batch_workspace_bytes(plan->p, guidance ? guidance->p : nullptr, rows);
 }
@@ -263,7 +267,8 @@ static int sample_common(const grlhip_plan* plan, const void* packed, int dtype,
     const size_t need = grlhip_workspace_bytes(plan, guidance, rows, dtype);
     if (!workspace || workspace_bytes < need) return fail(GRLHIP_ERR_WORKSPACE, "workspace too small: need " + std::to_string(need));
     SampleCall c{x0, cond, coef, dW, out_final, out_traj, rows, n_steps};
-    batch_sample(p, (const float*)packed, g, (const float*)guidance_packed, c, (float*)workspace, st, true, stages);
+    if (!g && !stages && wide_ok(p)) wide_sample(p, (const float*)packed, c, workspace, st);   // wide nets: row-major bf16 slab
+    else batch_sample(p, (const float*)packed, g, (const float*)guidance_packed, c, (float*)workspace, st, true, stages);
     HIP_TRY(hipGetLastError());
     return 0;
   }
