@@ -493,3 +493,9 @@ int grlhip_sample_ode_backward(const grlhip_plan* plan, const void* packed, int 
 }
 
 }  // extern "C"
+
+#ifdef WIDE_STAMPS
+extern "C" int grlhip_dbg_wide(unsigned long long* dst) {   // experiment builds only
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(grlhip::wd::wide_dbg), sizeof(unsigned long long) * 1024 * 8);
+}
+#endif
