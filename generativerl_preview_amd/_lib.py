@@ -66,6 +66,8 @@ PROTOTYPES = {
     "grlhip_net_backward": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "grlhip_sample_ode_backward": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp,
                                                   _vp, _sz, _vp]),
+    "grlhip_sample_stages_backward": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp,
+                                                  _vp, _sz, _vp]),
     "grlhip_cep_loss_fwd_bwd": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp,
                                                _i64, _vp, _sz, _vp]),
 }

@@ -492,6 +492,27 @@ int grlhip_sample_ode_backward(const grlhip_plan* plan, const void* packed, int 
   return 0;
 }
 
+int grlhip_sample_stages_backward(const grlhip_plan* plan, const void* packed, int dtype, const float* states,
+                                  const float* cond, const float* stage_table, int32_t n_stages, int64_t rows,
+                                  const float* grad_states, float* grad_x0, float* grad_flat, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  if (int rc = check_ready(plan, packed)) return rc;
+  const Plan* p = plan->p;
+  if (p->desc.kind != GRLHIP_NET_RESNET || p->tr_gx < 0) return fail(GRLHIP_ERR_INVALID, "sample_stages_backward needs a RESNET plan");
+  if (p->desc.out_dim != p->desc.x_dim) return fail(GRLHIP_ERR_INVALID, "sample_stages_backward needs out_dim == x_dim");
+  if (dtype != GRLHIP_F32) return fail(GRLHIP_ERR_UNSUPPORTED, "sample_stages_backward: only GRLHIP_F32 is implemented");
+  if (rows <= 0 || n_stages <= 0) return 0;
+  if (!states || !stage_table || !grad_states || !grad_flat) return fail(GRLHIP_ERR_INVALID, "null states/stage_table/grad_states/grad_flat");
+  if ((p->desc.cond_dim > 0) != (cond != nullptr))
+    return fail(GRLHIP_ERR_INVALID, "condition pointer does not match the plan's cond_dim");
+  const size_t need = grlhip_loss_workspace_bytes(plan, rows, dtype);
+  if (!workspace || workspace_bytes < need) return fail(GRLHIP_ERR_WORKSPACE, "workspace too small: need " + std::to_string(need));
+  StagesBwdCall c{states, cond, stage_table, grad_states, grad_x0, grad_flat, rows, n_stages};
+  stages_backward(p, (const float*)packed, c, (float*)workspace, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 }  // extern "C"
 
 #ifdef WIDE_STAMPS

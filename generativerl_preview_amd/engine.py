@@ -160,6 +160,22 @@ class NetPlan:
                                                        ws.numel(), _stream(dev)))
         return flat, gx0
 
+    def sample_stages_backward(self, packed, states, cond, table, grad_states):
+        """grlhip_sample_stages_backward -> (flat parameter gradient, d loss / d x0).  states: (n_stages + 1, R, D),
+        every stage's input state then the final one."""
+        n1, rows, D = states.shape
+        dev = states.device
+        states, grad_states = _f32c(states, "stage states"), _f32c(grad_states, "grad_states", (n1, rows, D))
+        cond, table = _f32c(cond, "condition"), _f32c(table.to(dev), "stage table", (n1 - 1, L.COEF_STRIDE))
+        flat = torch.zeros(L.lib().grlhip_grad_numel(self.handle), dtype=torch.float32, device=dev)
+        gx0 = torch.empty(rows, D, dtype=torch.float32, device=dev)
+        ws = self.train_workspace(rows, dev)
+        with torch.cuda.device(dev):
+            L.check(L.lib().grlhip_sample_stages_backward(self.handle, _ptr(packed), L.F32, _ptr(states), _ptr(cond),
+                                                          _ptr(table), n1 - 1, rows, _ptr(grad_states), _ptr(gx0),
+                                                          _ptr(flat), _ptr(ws), ws.numel(), _stream(dev)))
+        return flat, gx0
+
     def energy_grad(self, packed, t, x, cond, scale, dtype=L.F32):
         rows = x.shape[0]
         dev = x.device

@@ -203,6 +203,51 @@ class _DifferentiableOde(torch.autograd.Function):
         return (None, None, None, gx0 if ctx.needs_input_grad[3] else None, *grads)
 
 
+class _DifferentiableStages(torch.autograd.Function):
+    """DPMSolver stages with a grad_fn: forward = ONE grlhip_sample_stages call (fp32) that stores every stage's
+    input state, backward = ONE grlhip_sample_stages_backward call.  Returns the states (n_stages + 1, R, D)."""
+
+    @staticmethod
+    def forward(ctx, fn, condition, table, x0, *params):
+        m = fn.model
+        n = table.shape[0]
+        g_plan = g_packed = None
+        if fn.guidance is not None:
+            g_plan, g_packed = fn.guidance.plan, fn.guidance.packed(L.F32)
+        every = table.clone()
+        every[:, 9] = torch.arange(1, n + 1, dtype=torch.float32)   # emit slot i + 1 after every stage
+        _, states = m.plan.sample_stages(m.packed(L.F32), x0, condition, every, guidance=g_plan, guidance_packed=g_packed,
+                                         trajectory_slots=n + 1, dtype=L.F32)
+        ctx.fn, ctx.condition, ctx.table = fn, condition, table
+        ctx.save_for_backward(states)
+        return states
+
+    @staticmethod
+    def backward(ctx, grad_states):
+        (states,) = ctx.saved_tensors
+        m = ctx.fn.model
+        plan = m.plan
+        flat, gx0 = plan.sample_stages_backward(m.packed(L.F32), states, ctx.condition, ctx.table, grad_states)
+        named = m._named()
+        grads = []
+        for i, (name, shape) in enumerate(plan.params):
+            p = named[name]
+            if p.requires_grad:
+                off = L.lib().grlhip_grad_offset(plan.handle, i)
+                grads.append(flat[off:off + p.numel()].view(p.shape))
+            else:
+                grads.append(None)
+        return (None, None, None, gx0 if ctx.needs_input_grad[3] else None, *grads)
+
+
+def differentiable_stages(fn, condition, table, x0):
+    """States (n_stages + 1, R, D) of the stage table run from x0, differentiable with respect to the model's
+    parameters and x0 (not the condition; the guidance term is a constant, as in the reference)."""
+    named = fn.model._named()
+    params = [named[n] for n, _ in fn.model.plan.params]
+    return _DifferentiableStages.apply(fn, condition, table, x0, *params)
+
+
 class AffineModelFn:
     """A solver-facing model function that is affine in (net, x, dE/dx):
         m(t, x, c) = cn(t) net(t, x, c) + cx(t) x + cg(t) dE/dx(t, x, c).

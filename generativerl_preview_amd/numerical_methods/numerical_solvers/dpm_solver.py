@@ -4,7 +4,8 @@ configurations ship with (order 2, 17 function evaluations).
 The per-step algebra is a handful of scalar schedule values (half-logSNR, log-scale, std) computed on the CPU in
 fp32 exactly as the reference computes them on tensors.  Orders 1-3 of both solver types become a stage table that
 ONE ``grlhip_sample_stages`` call runs on the device (``_integrate_fused``; the last stage of order 3 "taylor" uses
-the second saved model value, ``W2``).  With ``with_grad=True`` the same stages are stepped from the host with
+the second saved model value, ``W2``).  With ``with_grad=True`` the same table runs in fp32 with every stage state kept and
+the backward is ONE ``grlhip_sample_stages_backward`` call; a model function without ``coefficients`` is stepped from the host with
 autograd on, each model evaluation being the differentiable HIP forward of the C ABI.
 Supported: ``method="singlestep"`` with orders 1-3, ``type`` "dpm_solver" / "dpm_solver++", ``solver_type``
 "dpm_solver" / "taylor", ``skip_type`` "time_uniform" / "time_quadratic".  The option values on which the
@@ -68,8 +69,9 @@ class DPMSolver:
                   steps: int = None, save_intermediate: bool = False, with_grad: bool = False):
         """dpm_solver.py:83-905.  ``x``: (B, ...) device tensor; returns the final state, or the stacked states
         (len(orders) + 1, B, ...) with ``save_intermediate=True``.  ``with_grad`` (the reference simply does not wrap
-        the call in ``no_grad``, diffusion_model.py:261-279): the stages run host-driven with autograd on -- every model
-        evaluation is the differentiable HIP forward (backward = grlhip_net_backward), the stage algebra is torch."""
+        the call in ``no_grad``, diffusion_model.py:261-279): the stage table with a grad_fn whose backward is one
+        grlhip_sample_stages_backward call; for a model function without ``coefficients`` the stages run host-driven
+        with autograd on (every model evaluation the differentiable HIP forward, the stage algebra torch)."""
         steps = steps if steps is not None else self.steps if self.steps is not None else 20
         if self.method != "singlestep":
             raise NotImplementedError("DPMSolver method '%s' (the reference's 'singlestep_fixed' fails on an unbound "
@@ -159,7 +161,9 @@ class DPMSolver:
         orders = self.get_orders_for_singlestep_solver(steps=steps, order=self.order)
         ts = self.get_time_steps(t_T=t_T, t_0=t_0, N=steps)
         fn = data_prediction_function if plus else noise_function
-        if not with_grad and self.fused and hasattr(fn, "coefficients") and x.is_cuda and x.dim() == 2:
+        if self.fused and hasattr(fn, "coefficients") and x.is_cuda and x.dim() == 2:
+            if with_grad:
+                return self._integrate_fused_with_grad(dp, fn, x, condition, orders, ts, save_intermediate)
             return self._integrate_fused(dp, fn, x, condition, orders, ts, save_intermediate)
         x_list = [x.clone()] if save_intermediate else None
         with torch.enable_grad() if with_grad else torch.no_grad():
@@ -188,6 +192,16 @@ class DPMSolver:
         final, traj = m.plan.sample_stages(m.packed(dtype), x, condition, table, guidance=g_plan, guidance_packed=g_packed,
                                            trajectory_slots=len(orders) + 1 if save_intermediate else 0, dtype=dtype)
         return traj if save_intermediate else final
+
+    def _integrate_fused_with_grad(self, dp, fn, x, condition, orders, ts, save_intermediate):
+        """``with_grad=True``: the same stage table in fp32, every stage's state kept, and a grad_fn whose backward is
+        ONE grlhip_sample_stages_backward call (gradients reach the model's parameters and ``x``)."""
+        from ...generative_models.fused import differentiable_stages
+        table = self.stage_table(dp, fn, orders, ts, True)
+        self.nfe += table.shape[0]
+        states = differentiable_stages(fn, condition, table, x)
+        ends = [0] + [i + 1 for i in range(table.shape[0]) if table[i, 9] >= 0]   # stages that end a solver step
+        return states[ends] if save_intermediate else states[-1]
 
     def stage_table(self, dp, fn, orders, ts, save_intermediate=True):
         """Orders 1-3, both solver types: every stage is

@@ -274,6 +274,21 @@ int grlhip_sample_ode_backward(const grlhip_plan* plan, const void* packed, int 
                                const float* grad_traj, float* grad_x0, float* grad_flat,
                                void* workspace, size_t workspace_bytes, void* stream);
 
+/* Replaces: torch autograd's backward through DPMSolver.integrate's stages when the caller differentiates a
+ * DPM-Solver sample (`sample(..., with_grad=True)` with a DPMSolver: diffusion_model/diffusion_model.py:261-279 ->
+ * grl/numerical_methods/numerical_solvers/dpm_solver.py:83-905, singlestep orders 1-3).  stage_table is the table a
+ * grlhip_sample_stages call ran (same row layout); states[n_stages+1][R][D] holds every stage's INPUT state
+ * (states[i] = the state stage i started from, states[n_stages] = the final one: the trajectory of a forward call
+ * whose table emits slot i+1 at every stage i); grad_states has the same shape (d loss / d states, zeros where
+ * unused).  Walks the table backwards, recomputing each stage's model evaluation and carrying the adjoints of the
+ * saved state / model values (xs, ms, ms2): grad_flat (+=) d loss / d theta, grad_x0[R][D] (may be NULL) =
+ * d loss / d x0.  The guidance column cg is not differentiated (the reference detaches the guidance term,
+ * energy_conditional_diffusion_model.py:87-92).  RESNET plans, GRLHIP_F32.  Workspace: grlhip_loss_workspace_bytes. */
+int grlhip_sample_stages_backward(const grlhip_plan* plan, const void* packed, int dtype, const float* states,
+                                  const float* cond, const float* stage_table, int32_t n_stages, int64_t rows,
+                                  const float* grad_states, float* grad_x0, float* grad_flat,
+                                  void* workspace, size_t workspace_bytes, void* stream);
+
 /* Replaces: the energy-guidance network's forward + autograd backward inside
  * EnergyConditionalDiffusionModel.energy_guidance_loss (contrastive energy prediction,
  * grl/generative_models/diffusion_model/energy_conditional_diffusion_model.py:1354-1394) for a CONCAT_MLP plan.

@@ -83,17 +83,28 @@ def test_workspace_size_follows_the_slab_pitch():
     any large batch); batches beyond the chunk size are processed in chunks of 262 144 rows.  Seen from outside: the
     workspace size is a step function of the row count with exactly those steps, and never decreases."""
     from generativerl_preview_amd.engine import NetPlan
-    plan = NetPlan(L.NET_RESNET, 64, 64, 0, 32, 0, 0, [1024])
+    plan = NetPlan(L.NET_RESNET, 64, 64, 0, 32, 0, 0, [128])
     size = lambda rows: L.lib().grlhip_workspace_bytes(plan.handle, None, rows, L.BF16)  # noqa: E731
     assert size(1) == size(128) < size(129) == size(256)
     assert size(32768 - 127) == size(32768) < size(32769) == size(32768 + 256)
     assert size(32768 + 257) == size(32768 + 512) > size(32768 + 256)
     per_row = (size(32768 + 512) - size(32768 + 256)) // 256
-    assert per_row > 4 * 1024 and (size(256) - size(128)) == 128 * per_row     # bytes per slab row, same below the switch
+    assert per_row > 4 * 128 and (size(256) - size(128)) == 128 * per_row      # bytes per slab row, same below the switch
     assert size(262144) == size(10 ** 7)                                       # chunked beyond 262 144 rows
     prev = 0
     for rows in range(1, 70000, 97):
         cur = size(rows)
+        assert cur >= prev
+        prev = cur
+    # a wide net (hidden >= 256) also has the dense bf16 buffers of the wide engine (256-row pitch at any size): the
+    # workspace is the larger of the two layouts -- still a never-decreasing step function, chunked at 262 144 rows
+    wide = NetPlan(L.NET_RESNET, 64, 64, 0, 32, 0, 0, [1024])
+    wsize = lambda rows: L.lib().grlhip_workspace_bytes(wide.handle, None, rows, L.BF16)  # noqa: E731
+    assert wsize(32768 + 1) == wsize(32768 + 256) < wsize(32768 + 257)
+    assert wsize(262144) == wsize(10 ** 7) > size(262144)
+    prev = 0
+    for rows in range(1, 70000, 97):
+        cur = wsize(rows)
         assert cur >= prev
         prev = cur
 
