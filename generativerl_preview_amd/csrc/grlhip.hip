@@ -125,10 +125,16 @@ int grlhip_plan_program_info(const grlhip_plan* plan, int program, int32_t* n_op
   int launches = 0;
   for (size_t i = 0; i < prog.size(); ++i, ++launches) {
     if (batch_fusable(p, prog, i)) ++i;
-    else if (prog[i].type == OP_DW) ++launches;   // partial tiles + the ordered reduce
+    else if (prog[i].type == OP_DW || prog[i].type == OP_HEAD_BWD) ++launches;   // partials + the ordered reduce
   }
   if (n_ops) *n_ops = (int32_t)prog.size();
   if (n_launches) *n_launches = launches;
+  return 0;
+}
+
+int grlhip_plan_set_fourier_grad(grlhip_plan* plan, int enable) {
+  if (!plan || !plan->p) return fail(GRLHIP_ERR_INVALID, "null plan");
+  plan->p->fourier_grad = enable != 0;
   return 0;
 }
 

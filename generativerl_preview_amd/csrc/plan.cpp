@@ -260,7 +260,7 @@ Plan* build_plan(const grlhip_net_desc& d, std::string& err) {
     }
   } else if (d.kind == GRLHIP_NET_CONCAT_MLP || qnet) {
     const int L = d.n_hidden;
-    const int ACT = qnet ? F_RELU_OUT : F_SILU_OUT, ACT_BWD = qnet ? OP_RELU_BWD : OP_SILU_BWD;
+    const int ACT = qnet ? F_RELU_OUT : F_SILU_OUT;
     const int K0 = d.t_dim + d.x_dim + d.cond_dim;
     if (d.out_dim != 1) { err = "CONCAT_MLP energy nets must have out_dim == 1"; delete p; return nullptr; }
     p->temb_off = b.alloc(K0);  // [t_emb | x | c] contiguous (concat order intrinsic_model.py:69)
@@ -323,11 +323,16 @@ Plan* build_plan(const grlhip_net_desc& d, std::string& err) {
       p->tr_out = t.alloc(1);
       p->tr_gout = t.alloc(1);
       const int hmax = *std::max_element(d.hidden, d.hidden + L);
-      const int g_a = t.alloc(hmax), g_z = t.alloc(hmax);
+      const int gz[2] = {t.alloc(hmax), t.alloc(hmax)};               // dZ of consecutive layers alternate between the two
       p->tr_gtc = qnet ? -1 : t.alloc(d.t_dim);
       int tin = p->tr_temb;
       for (int i = 0; i < L; ++i) { t.linear(TF, lin[i], tin, ta[i], -1, ACT | F_SAVE_PRE, tz[i]); tin = ta[i]; }
-      t.linear(TF, lin[L], tin, p->tr_out, -1, 0);
+      {                                                                // f = w_last . a_L + b: matrix-vector
+        Op o{};
+        o.type = OP_HEAD_FWD; o.K = d.hidden[L - 1]; o.N = 1; o.w = (int32_t)p->linears[lw].w_off;
+        o.b = (int32_t)p->linears[lin[L]].b_off; o.in = tin; o.out = p->tr_out; o.add = -1; o.pre = -1; o.lin = lin[L];
+        TF.push_back(o);
+      }
       auto dw = [&](int li, int dzo, int ino) {
         const LinearDesc l = p->linears[li];
         Op o{};
@@ -336,26 +341,33 @@ Plan* build_plan(const grlhip_net_desc& d, std::string& err) {
         o.in = ino; o.add = dzo; o.out = -1; o.pre = l.K; o.lin = li;
         TB.push_back(o);
       };
-      dw(lin[L], p->tr_gout, ta[L - 1]);
-      t.linear(TB, lw, p->tr_gout, g_a, -1, 0);                       // da_L = w_last * df
+      int cur = 0;
+      {                                                                // dz_L, d w_last, d b_last in one pass
+        Op o{};
+        o.type = OP_HEAD_BWD; o.K = d.hidden[L - 1]; o.N = 1; o.w = (int32_t)p->linears[lw].w_off; o.b = -1;
+        o.in = ta[L - 1]; o.out = gz[cur]; o.add = p->tr_gout; o.pre = tz[L - 1]; o.flags = qnet ? F_RELU_OUT : 0;
+        o.lin = lin[L];
+        TB.push_back(o);
+      }
       for (int i = L - 1; i >= 0; --i) {
-        t.eltwise(TB, ACT_BWD, d.hidden[i], tz[i], g_z, g_a);         // dz_i = da_i * act'(z_i)
-        dw(lin[i], g_z, i ? ta[i - 1] : p->tr_temb);
+        dw(lin[i], gz[cur], i ? ta[i - 1] : p->tr_temb);
         const LinearDesc li = p->linears[lin[i]];
         if (i) {
+          // dz_{i-1} = (W_i^T dz_i) * act'(z_{i-1}) from the GEMM's epilogue; da_{i-1} itself is not stored
           int lt = t.add_matrix(li.K, li.N, li.p_w, -1, 0, li.K, 1);  // W_i^T
-          t.linear(TB, lt, g_z, g_a, -1, 0);
+          t.linear(TB, lt, gz[cur], -1, tz[i - 1], F_DSILU | F_NO_OUT | (qnet ? F_RELU_OUT : 0), gz[cur ^ 1]);
+          cur ^= 1;
         } else if (!qnet) {
           int lt = t.add_matrix(d.t_dim, li.N, li.p_w, -1, 0, li.K, 1);  // (W_1[:, t_emb cols])^T
-          t.linear(TB, lt, g_z, p->tr_gtc, -1, 0);
+          t.linear(TB, lt, gz[cur], p->tr_gtc, -1, F_FOURIER_ONLY);
         }
       }
-      // trailing op, run only when the caller asks for d/dx (grlhip_net_backward's grad_x): g_z still holds dz_0
+      // trailing op, run only when the caller asks for d/dx (grlhip_net_backward's grad_x): gz[cur] still holds dz_0
       {
         const LinearDesc l0 = p->linears[lin[0]];
         p->tr_gx = t.alloc(d.x_dim);
         int lx0 = t.add_matrix(d.x_dim, l0.N, l0.p_w, -1, d.t_dim, l0.K, 1);  // (W_1[:, x cols])^T
-        t.linear(TB, lx0, g_z, p->tr_gx, -1, 0);
+        t.linear(TB, lx0, gz[cur], p->tr_gx, -1, 0);
         p->train_bwd_dx_ops = 1;
       }
       p->train_slab_features = up(t.bump, 2);

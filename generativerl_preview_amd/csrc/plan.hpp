@@ -24,12 +24,21 @@ enum OpType : int32_t {
   OP_SILU_BWD_CONST = 4, // out[n] = wts[w + n] * silu'(in[n])
   OP_DW = 5,             // grad[w + n*pre + k] += sum_rows slab[add + n] * slab[in + k]; grad[b + n] += sum_rows slab[add + n]
   OP_ADD = 6,            // out[n] += in[n]
-  OP_RELU_BWD = 7        // out[n] = slab[add + n] * (in[n] > 0)
+  OP_RELU_BWD = 7,       // out[n] = slab[add + n] * (in[n] > 0)
+  // the 1-wide output layer of an energy / Q net as matrix-vector work (K features):
+  OP_HEAD_FWD = 8,       // slab[out] = wts[b] + sum_k wts[w + k] * slab[in + k]
+  // its backward from g = slab[add] (one feature): slab[out + k] = g * wts[w + k] * act'(slab[pre + k]) (the dZ of the
+  // layer below; act = ReLU with F_RELU_OUT, else SiLU); grad[lin's weight + k] += sum_rows g * slab[in + k];
+  // grad[bias] += sum_rows g.  Op.lin = the output linear (its parameter indices give the gradient offsets)
+  OP_HEAD_BWD = 9
 };
 enum OpFlags : int32_t { F_SILU_OUT = 1, F_SAVE_PRE = 2, F_ACCUM = 4, F_RELU_OUT = 8,
                          // backward: besides out = A in (+bias), pre = out * SiLU'(slab[add]) -- the dZ of the layer below,
                          // whose pre-activation sits at `add` (nothing is added to out)
-                         F_DSILU = 16 };
+                         // (with F_RELU_OUT: ReLU' instead of SiLU'; with F_NO_OUT: out itself is not stored)
+                         F_DSILU = 16, F_NO_OUT = 32,
+                         // the op only feeds the gradient of the Fourier frequencies: skipped unless Plan::fourier_grad
+                         F_FOURIER_ONLY = 64 };
 
 struct Op {
   int32_t type, K, N, w, b, in, out, add, flags, pre;  // pre: where z (pre-activation) is kept (F_SAVE_PRE)
@@ -65,6 +74,7 @@ struct Plan {
   int32_t tr_temb = 0, tr_x = 0, tr_c = -1, tr_out = 0, tr_gout = 0, tr_gtc = 0;
   int32_t tr_gx = -1;            // d loss / d x (RESNET; written by the last train_bwd_dx_ops ops of train_bwd)
   int32_t train_bwd_dx_ops = 0;  // trailing ops of train_bwd that only the differentiable integrator needs
+  bool fourier_grad = true;      // compute d loss / d (Fourier frequencies) in the training entry points
   void* d_train_fwd = nullptr;
   void* d_train_bwd = nullptr;
   int32_t slab_features = 0;

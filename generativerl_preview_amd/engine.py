@@ -52,6 +52,7 @@ class NetPlan:
         self.device = device
         self.handle = h
         self._ws = {}
+        self.fourier_grad = True     # the library's default (grlhip_plan_set_fourier_grad)
         n = L.lib().grlhip_plan_num_params(h)
         self.params = []
         buf = ctypes.create_string_buffer(256)
@@ -59,6 +60,12 @@ class NetPlan:
             r, c = ctypes.c_int32(), ctypes.c_int32()
             L.check(L.lib().grlhip_plan_param_info(h, i, buf, 256, ctypes.byref(r), ctypes.byref(c)))
             self.params.append((buf.value.decode(), (r.value, c.value) if c.value else (r.value,)))
+
+    def set_fourier_grad(self, enable):
+        """Whether the training entry points compute the gradient of the time encoder's frequencies."""
+        if enable != self.fourier_grad:
+            L.check(L.lib().grlhip_plan_set_fourier_grad(self.handle, int(enable)))
+            self.fourier_grad = enable
 
     def __del__(self):
         try:

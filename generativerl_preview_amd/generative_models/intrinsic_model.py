@@ -77,6 +77,9 @@ class IntrinsicModel(nn.Module):
                 self._plan = NetPlan(L.NET_CONCAT_MLP, x_dim, d["out_dim"], c_dim, te.embed_dim, 0, 0, d["hidden"], device=dev)
             else:
                 raise NotImplementedError("no fused kernel for backbone %s" % type(bb).__name__)
+        # the Fourier frequencies are frozen unless the encoder was built with requires_grad=True (encoders.py:53-66):
+        # the training entry points then skip the work that only feeds their gradient
+        self._plan.set_fourier_grad(bool(self.model["t_encoder"].W.requires_grad))
         return self._plan
 
     def set_io_dims(self, x_dim, cond_dim):

@@ -84,6 +84,12 @@ int grlhip_plan_num_params(const grlhip_plan* plan);
 int grlhip_plan_param_info(const grlhip_plan* plan, int index, char* name_buf, size_t name_buf_len,
                            int32_t* rows, int32_t* cols);
 
+/* Replaces: the `requires_grad` argument of GaussianFourierProjectionTimeEncoder (grl/neural_network/encoders.py:53-66;
+ * False by default and in every shipped configuration): with enable == 0 the training entry points
+ * (grlhip_loss_fwd_bwd, grlhip_cep_loss_fwd_bwd, grlhip_net_backward, grlhip_sample_*_backward) leave the gradient slot
+ * of "t_encoder.W" untouched and skip the work that only feeds it.  Default: enabled. */
+int grlhip_plan_set_fourier_grad(grlhip_plan* plan, int enable);
+
 /* Introspection (no counterpart in the reference; used by the tests and to size stream captures): the number of
  * ops of one of the plan's programs (0 forward, 1 energy forward + input gradient, 2 training forward,
  * 3 training backward) and the number of kernel launches the batch engine turns it into per pass (a plain
