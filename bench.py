@@ -138,7 +138,7 @@ def f32_roofline(tf):
             "peak_note": "dense bf16 MFMA peak / 6 MFMAs per fp32 product", "frac_of_fp32_mfma_peak_157.3": tf / 157.3}
 
 
-PMC_PROFILE = "profiles/r02_bench_pmc.json"
+PMC_PROFILE = "profiles/r03_bench_pmc.json"
 
 
 def pmc_traffic(rows):
@@ -229,7 +229,11 @@ def c3_training(ranks, dry=False, steps=20, warmup=5):
     torch.manual_seed(0)    # identical initial weights on every rank
     m3 = G.IndependentConditionalFlowModel(cfg).to(device)
     fg = attach_flat_grads(m3.model)   # every .grad is a view of ONE flat buffer: one zero, one all-reduce
-    opt = torch.optim.Adam(m3.parameters(), lr=1e-4)
+    if dry:
+        opt = torch.optim.Adam(m3.parameters(), lr=1e-4)
+    else:                              # Adam over ONE flat parameter buffer: one launch (grlhip_adam_step)
+        from generativerl_preview_amd.optim import FlatAdam
+        opt = FlatAdam(m3.model, lr=1e-4)
     B = (8 + 5 * rank) if dry else 65536
     gen = torch.Generator(device=device).manual_seed(11 + rank)
     x1 = torch.rand(B, 6, device=device, generator=gen) * 2 - 1

@@ -3,6 +3,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -63,6 +64,45 @@ int check_ready(const grlhip_plan* plan, const void* packed) {
 
 }  // namespace
 
+// torch.optim.Adam's update (amsgrad / maximize off) over flat buffers, one thread per 4 elements
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct AdamArgs {
+  float* p; const float* g; float* m; float* v; int64_t n;
+  float b1, b2, eps, wd, step_size, bc2_sqrt;
+};
+__global__ __launch_bounds__(256) void k_adam_step(AdamArgs a) {
+  auto one = [&](int64_t i) {
+    float g = a.g[i];
+    const float p = a.p[i];
+    if (a.wd != 0.f) g = fmaf(a.wd, p, g);
+    const float m = a.m[i] + (g - a.m[i]) * (1.f - a.b1);                 // exp_avg.lerp_(grad, 1 - beta1)
+    const float v = fmaf(a.b2, a.v[i], (1.f - a.b2) * g * g);              // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    a.m[i] = m; a.v[i] = v;
+    a.p[i] = p - a.step_size * (m / (sqrtf(v) / a.bc2_sqrt + a.eps));
+  };
+  const int64_t n4 = a.n / 4;
+  const bool aligned = (((size_t)a.p | (size_t)a.g | (size_t)a.m | (size_t)a.v) & 15) == 0;
+  if (aligned) {
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (int64_t)gridDim.x * 256) {
+      const f32x4 g4 = *(const f32x4*)(a.g + 4 * q), p4 = *(const f32x4*)(a.p + 4 * q);
+      const f32x4 m4 = *(const f32x4*)(a.m + 4 * q), v4 = *(const f32x4*)(a.v + 4 * q);
+      f32x4 po, mo, vo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float g = g4[e];
+        if (a.wd != 0.f) g = fmaf(a.wd, p4[e], g);
+        mo[e] = m4[e] + (g - m4[e]) * (1.f - a.b1);
+        vo[e] = fmaf(a.b2, v4[e], (1.f - a.b2) * g * g);
+        po[e] = p4[e] - a.step_size * (mo[e] / (sqrtf(vo[e]) / a.bc2_sqrt + a.eps));
+      }
+      *(f32x4*)(a.m + 4 * q) = mo; *(f32x4*)(a.v + 4 * q) = vo; *(f32x4*)(a.p + 4 * q) = po;
+    }
+    for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) one(i);
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) one(i);
+  }
+}
+
 extern "C" {
 
 const char* grlhip_last_error(void) { return g_err.c_str(); }
@@ -122,11 +162,12 @@ int grlhip_plan_program_info(const grlhip_plan* plan, int program, int32_t* n_op
   if (!plan || !plan->p || program < 0 || program > 3) return fail(GRLHIP_ERR_INVALID, "program must be 0..3");
   const Plan* p = plan->p;
   const std::vector<Op>& prog = program == 0 ? p->fwd : program == 1 ? p->grad : program == 2 ? p->train_fwd : p->train_bwd;
-  int launches = 0;
+  int launches = 0, reduces = 0;
   for (size_t i = 0; i < prog.size(); ++i, ++launches) {
     if (batch_fusable(p, prog, i)) ++i;
-    else if (prog[i].type == OP_DW || prog[i].type == OP_HEAD_BWD) ++launches;   // partials + the ordered reduce
+    else if (prog[i].type == OP_DW || prog[i].type == OP_HEAD_BWD) ++reduces;   // partials now, ordered reduce at the end
   }
+  launches += (reduces + bt::REDUCE_BATCH - 1) / bt::REDUCE_BATCH;                // one batched reduce per 24 gradients
   if (n_ops) *n_ops = (int32_t)prog.size();
   if (n_launches) *n_launches = launches;
   return 0;
@@ -515,6 +556,20 @@ int grlhip_sample_stages_backward(const grlhip_plan* plan, const void* packed, i
   if (!workspace || workspace_bytes < need) return fail(GRLHIP_ERR_WORKSPACE, "workspace too small: need " + std::to_string(need));
   StagesBwdCall c{states, cond, stage_table, grad_states, grad_x0, grad_flat, rows, n_stages};
   stages_backward(p, (const float*)packed, c, (float*)workspace, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int grlhip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, int64_t step, void* stream) {
+  if (n <= 0) return 0;
+  if (!params || !grads || !exp_avg || !exp_avg_sq) return fail(GRLHIP_ERR_INVALID, "null params/grads/exp_avg/exp_avg_sq");
+  if (step < 1) return fail(GRLHIP_ERR_INVALID, "adam_step: step counts from 1");
+  // bias corrections in double on the host, as torch.optim.Adam computes them for a Python-float step
+  const double bc1 = 1.0 - std::pow((double)beta1, (double)step), bc2 = 1.0 - std::pow((double)beta2, (double)step);
+  AdamArgs a{params, grads, exp_avg, exp_avg_sq, n, beta1, beta2, eps, weight_decay, (float)(lr / bc1), (float)std::sqrt(bc2)};
+  const int64_t blocks = std::min<int64_t>((n + 1023) / 1024, 4096);
+  hipLaunchKernelGGL(k_adam_step, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
   return 0;
 }

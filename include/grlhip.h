@@ -308,6 +308,16 @@ int grlhip_cep_loss_fwd_bwd(const grlhip_plan* plan, const void* packed, int dty
                             const float* group_weight, float* loss_groups, float* grad_flat, int64_t rows,
                             void* workspace, size_t workspace_bytes, void* stream);
 
+/* Replaces: torch.optim.Adam.step (amsgrad and maximize off) for the optimizers the reference's training loops build
+ * over one network's parameters (grl/algorithms/qgpo.py:554,637,642, grl/algorithms/gmpo.py:788,942,946,1061), when the
+ * parameters and their gradients live in flat fp32 buffers (generativerl_preview_amd/optim.py: the gradient layout of
+ * grlhip_grad_offset): ONE launch over n elements instead of the optimizer's per-tensor kernels,
+ *   g += weight_decay p;  m += (g - m)(1 - beta1);  v = beta2 v + (1 - beta2) g g;
+ *   p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps).
+ * `step` counts from 1.  All four buffers are device pointers of n floats; exp_avg / exp_avg_sq start at zero. */
+int grlhip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, int64_t step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,7 +43,8 @@ def main():
     torch.manual_seed(0)  # identical initial weights on every rank
     m = G.IndependentConditionalFlowModel(dict(gl.icfm_cfg(6, [512, 256, 128], 17), device=device)).to(device)
     fg = attach_flat_grads(m.model)   # .grad of every parameter is a view of ONE flat buffer
-    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    from generativerl_preview_amd.optim import FlatAdam
+    opt = FlatAdam(m.model, lr=1e-4)   # ONE launch over the flat parameter buffer (grlhip_adam_step)
     B = args.batch
     gen = torch.Generator(device=device).manual_seed(1 + rank)
     x1 = torch.rand(B, 6, device=device, generator=gen) * 2 - 1

@@ -18,7 +18,7 @@ except Exception as e:  # noqa: BLE001
     rows = []
 if rows:
     # steps are delimited by the Fourier-gradient kernel (once per step); take the last 6 whole steps
-    marks = [i for i, r in enumerate(rows) if "k_bt_fourier_grad" in r[0]]
+    marks = [i for i, r in enumerate(rows) if "k_bt_loss" in r[0]]   # the loss kernel runs once per step (one chunk)
     steps = []
     for a, b in zip(marks[:-1], marks[1:]):
         seg = rows[a:b]

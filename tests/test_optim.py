@@ -1,0 +1,49 @@
+"""FlatAdam (grlhip_adam_step: Adam over one flat parameter buffer, one launch per step) against torch.optim.Adam on the
+same model, losses and draws."""
+import copy
+
+import pytest
+import torch
+
+import util_models as um
+
+DEV = "cuda:0"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("weight_decay", [0.0, 0.01])
+def test_gpu_flat_adam_matches_torch_adam(weight_decay):
+    from generativerl_preview_amd.optim import FlatAdam
+    name = "small_icfm"
+    kind, cfg, a = um.build(name, DEV)
+    kind, cfg, b = um.build(name, DEV)
+    b.load_state_dict(copy.deepcopy(a.state_dict()))
+    ref = torch.optim.Adam([p for p in a.parameters() if p.requires_grad], lr=3e-3, betas=(0.8, 0.95), eps=1e-7,
+                           weight_decay=weight_decay)
+    opt = FlatAdam(b.model, lr=3e-3, betas=(0.8, 0.95), eps=1e-7, weight_decay=weight_decay)
+    frozen = b.model.model["t_encoder"].W.detach().clone()
+    gen = torch.Generator().manual_seed(4)
+    B = 300
+    for step in range(4):
+        x0, x1 = torch.randn(B, 6, generator=gen).to(DEV), torch.rand(B, 6, generator=gen).to(DEV)
+        cond, t, eps = torch.randn(B, 17, generator=gen).to(DEV), torch.rand(B, generator=gen).to(DEV), torch.randn(B, 6, generator=gen).to(DEV)
+        ref.zero_grad()
+        la = a.flow_matching_loss(x0, x1, cond, t=t, noise=eps)
+        la.backward()
+        ref.step()
+        opt.zero_grad()
+        lb = b.flow_matching_loss(x0, x1, cond, t=t, noise=eps)
+        lb.backward()
+        opt.step()
+        assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(la)), (step, float(la), float(lb))
+    pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+    assert len(pa) > 10
+    for k in pa:
+        scale = float(pa[k].abs().max()) + 1e-12
+        assert float((pa[k] - pb[k]).abs().max()) <= 2e-5 * scale, k
+    assert torch.equal(b.model.model["t_encoder"].W.detach(), frozen)      # frozen parameters are not touched
+    # the parameters are views of one buffer, the state dict still has the reference's keys and shapes
+    assert all(p.data_ptr() >= opt.flat_params.data_ptr() for p in b.model.parameters())
+    assert {k: tuple(v.shape) for k, v in a.state_dict().items()} == {k: tuple(v.shape) for k, v in b.state_dict().items()}
+    sd = opt.state_dict()
+    assert sd["step"] == 4 and float(sd["exp_avg"].abs().max()) > 0
