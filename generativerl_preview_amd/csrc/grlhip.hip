@@ -187,7 +187,7 @@ int64_t grlhip_grad_offset(const grlhip_plan* plan, int index) {
 
 size_t grlhip_packed_bytes(const grlhip_plan* plan, int dtype) {
   if (!plan || !plan->p) return 0;
-  if (dtype == GRLHIP_F32) return (size_t)plan->p->packed_floats * sizeof(float);
+  if (dtype == GRLHIP_F32) return f32_packed_bytes(plan->p);
   // bf16 on a shape without a fused kernel runs the batch engine with bf16 MFMAs on the fp32 image
   if (dtype == GRLHIP_BF16)
     return bf16_fused_ok(plan->p) ? bf16_packed_bytes(plan->p) : wide_ok(plan->p) ? wide_packed_bytes(plan->p) : batch_bf16_packed_bytes(plan->p);
@@ -229,6 +229,26 @@ int grlhip_pack_weights(const grlhip_plan* plan, const void* const* params, int 
   if (half)
     hipLaunchKernelGGL(k_copy_pad_f32, dim3(1), dim3(64), 0, st, (const float*)params[0], dst + p->fourier_off, half,
                        (int)(p->packed_floats - p->fourier_off));
+  if (dtype == GRLHIP_F32) {   // the split image of the fp32 GEMMs (after the fp32 image on the same stream)
+    SplitBatch sb{};
+    auto sflush = [&]() {
+      if (sb.n) hipLaunchKernelGGL(k_split_many, dim3((unsigned)sb.first_block[sb.n]), dim3(256), 0, st, sb);
+      sb.n = 0;
+    };
+    __bf16* base = (__bf16*)((char*)packed + split_base_bytes(p));
+    for (size_t i = 0; i < p->linears.size(); ++i) {
+      const LinearDesc& l = p->linears[i];
+      SplitArgs& a = sb.a[sb.n];
+      a.src = dst + l.w_off; a.dst = base + p->split_off[i]; a.Npad = l.Npad; a.Kpad = l.Kpad;
+      a.np3 = (l.Npad + 127) / 128 * 128; a.tiles = (l.Kpad + 15) / 16;
+      const int64_t total = (int64_t)a.tiles * a.np3;
+      const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256);
+      if (sb.n == 0) sb.first_block[0] = 0;
+      sb.first_block[sb.n + 1] = sb.first_block[sb.n] + blocks;
+      if (++sb.n == PACK_BATCH) sflush();
+    }
+    sflush();
+  }
   if (dtype == GRLHIP_BF16) batch_mirror_weights(p, dst, st);   // (after the fp32 image on the same stream)
   if (dtype == GRLHIP_BF16 && wide_ok(p)) wide_pack(p, dst, st);   // row-major bf16 engine of the wide nets (engine_wide.hip.inc)
   HIP_TRY(hipGetLastError());

@@ -382,6 +382,10 @@ Plan* build_plan(const grlhip_net_desc& d, std::string& err) {
   p->packed_floats = b.woff;
   p->slab_features = up(b.bump, 2);
   if (p->packed_floats >= (int64_t)1 << 31) { err = "network too large"; delete p; return nullptr; }
+  for (const LinearDesc& l : p->linears) {
+    p->split_off.push_back(p->split_elems);
+    p->split_elems += (int64_t)up(l.Kpad, 16) / 16 * 3 * up(l.Npad, 128) * 16;
+  }
   return p;
 }
 

@@ -81,6 +81,11 @@ struct Plan {
   int32_t temb_off = 0, x_off = 0, c_off = 0, out_off = 0, gradx_off = 0;
   int64_t fourier_off = 0;   // offset of W (t_dim/2 floats) in the fp32 image
   int64_t packed_floats = 0; // size of the fp32 image
+  // GRLHIP_F32 packs carry, behind the fp32 image, every matrix pre-split into its three bf16 pieces in the order the
+  // fp32 GEMM stages them: [16-k tile][piece][row, padded to 128][16 k] (engine_batch: k_bt_gemm_x6).  Offsets in bf16
+  // elements from the start of that region, per linear
+  std::vector<int64_t> split_off;
+  int64_t split_elems = 0;
   int64_t grad_numel = 0;
   // device copies of the programs (uploaded at creation)
   void* d_fwd = nullptr;

@@ -11,6 +11,7 @@
 #include <cmath>
 #include "plan.hpp"
 namespace grlhip { inline int device_cus() { return 256; } }
+#include "pack_f32.hip.inc"
 #include "engine_batch.hip.inc"
 namespace grlhip { namespace bt {
 #include "gemm_x6_two_barrier.inc"
@@ -26,13 +27,21 @@ int main(int argc, char** argv) {
   hipMemcpy(A, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   std::vector<float> hb((size_t)K * 4096); for (auto& v : hb) v = (rand() % 2001 - 1000) * 1e-3f;
   for (int64_t o = 0; o < K * ld; o += hb.size()) hipMemcpy(B + o, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
+  // the weights pre-split into their three bf16 pieces (what grlhip_pack_weights puts behind a GRLHIP_F32 image)
+  __bf16* A3; hipMalloc(&A3, (size_t)(K / 16) * 3 * M * 16 * 2);
+  {
+    SplitBatch sb{};
+    sb.a[0] = SplitArgs{A, A3, M, K, M, K / 16};
+    sb.first_block[0] = 0; sb.first_block[1] = 64; sb.n = 1;
+    hipLaunchKernelGGL(k_split_many, dim3(64), dim3(256), 0, 0, sb);
+  }
   const int only_ns = argc > 2 ? atoi(argv[2]) : 0;   // 0: both
   hipFuncSetAttribute((const void*)bt::k_bt_gemm_x6<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bt::gemm_lds_bytes<2>());
   for (int ns = 2; ns <= 4; ++ns)   // 4: the pipelined kernel (16-k tiles, double-buffered LDS images)
   for (int mode = 0; mode < 3; ++mode) {
     if (only_ns && ns != only_ns) continue;
     bt::GemmArgs g{};
-    g.A = A; g.bias = bias; g.B = B; g.C = C; g.M = M; g.K = K; g.lda = M; g.ld = ld;
+    g.A = A; g.bias = bias; g.B = B; g.C = C; g.M = M; g.K = K; g.lda = M; g.ld = ld; g.A3 = A3; g.np3 = M;
     g.pre = mode >= 1 ? pre : nullptr; g.add = mode >= 2 ? add : nullptr; g.flags = mode >= 1 ? (F_SILU_OUT | F_SAVE_PRE) : 0;
     const dim3 grid((unsigned)((ld / bt::BN) * ((M + bt::BM - 1) / bt::BM)));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -53,7 +62,7 @@ int main(int argc, char** argv) {
   }
   {  // the pipelined kernel accumulates the same products in the same order: bit-identical outputs expected
     bt::GemmArgs g{};
-    g.A = A; g.bias = bias; g.B = B; g.C = C; g.M = M; g.K = K; g.lda = M; g.ld = ld;
+    g.A = A; g.bias = bias; g.B = B; g.C = C; g.M = M; g.K = K; g.lda = M; g.ld = ld; g.A3 = A3; g.np3 = M;
     g.pre = pre; g.add = add; g.flags = F_SILU_OUT | F_SAVE_PRE;
     const dim3 grid((unsigned)((ld / bt::BN) * ((M + bt::BM - 1) / bt::BM)));
     std::vector<float> c0((size_t)M * 4096), c1((size_t)M * 4096);
