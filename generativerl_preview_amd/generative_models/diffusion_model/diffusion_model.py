@@ -245,10 +245,16 @@ class DiffusionModel(nn.Module):
 
     def sample_with_log_prob(self, t_span: torch.Tensor, batch_size=None, condition=None, with_grad: bool = False,
                              solver_config=None):
-        """diffusion_model.py:1161-1189"""
+        """diffusion_model.py:1161-1189.  ``with_grad=True`` differentiates the SAMPLING part only: the likelihood of a
+        differentiable sample needs second derivatives of the network, which the library does not have (``log_prob``
+        raises for it), so the log-probability is returned without a grad_fn and a warning says so."""
         x = self.sample_forward_process(t_span=t_span, batch_size=batch_size, condition=condition, with_grad=with_grad,
                                         solver_config=solver_config)[-1]
-        return x, self.log_prob(x=x, condition=condition, with_grad=with_grad)
+        if with_grad:
+            import warnings
+            warnings.warn("sample_with_log_prob(with_grad=True): the sample is differentiable, its log-probability is "
+                          "computed without gradient (INTEGRATION.md, known deviations)")
+        return x, self.log_prob(x=x.detach() if with_grad else x, condition=condition, with_grad=False)
 
     # ------------------------------------------------------------------ training
     def dpo_loss(self, ref_dm, data, beta, t=None, noise=None):

@@ -871,6 +871,10 @@ def test_log_prob_vs_golden(name):
               what=pre + "log_prob default grid", rel=True)
         xs, lp = m.sample_with_log_prob(t_span=torch.linspace(0.0, 1.0, 11), batch_size=4)
         assert tuple(xs.shape) == (4, cfg["x_size"]) and tuple(lp.shape) == (4,) and bool(torch.isfinite(lp).all())
+        # with_grad=True: the sample carries a grad_fn, the log-probability does not (and a warning says so)
+        with pytest.warns(UserWarning, match="without gradient"):
+            xs, lp = m.sample_with_log_prob(t_span=torch.linspace(0.0, 1.0, 11), batch_size=4, with_grad=True)
+        assert xs.requires_grad and not lp.requires_grad and bool(torch.isfinite(lp).all())
     if kind == "icfm":
         xs, lp = m.sample_with_log_prob(t_span=torch.linspace(0.0, 1.0, 11), x_0=x, condition=cond)
         assert tuple(xs.shape) == tuple(x.shape) and tuple(lp.shape) == (x.shape[0],) and bool(torch.isfinite(lp).all())
