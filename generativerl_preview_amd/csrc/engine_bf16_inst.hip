@@ -28,6 +28,11 @@ using GuideSel = GuideQgpo;
 using BodySel = AsmBodyFor<CfgSel, GuideSel>::type;
 #define B16_CAT2(a, b, c, d, e, f) a##b##c##d##e##f
 #define B16_CAT(a, b, c, d, e, f) B16_CAT2(a, b, c, d, e, f)
+#if B16_VARIANT == 0 && B16_EXTRA == 0 && B16_GUIDE == 0
+// what the generated bodies of this library expect from the packer (engine_bf16_host.hip.inc, bf16_pack): 1 = the
+// time-MLP bias of every residual block folded into its dense2 bias
+int b16_body_folds_time_bias() { return B16_GEN_FOLD_TIME_BIAS; }
+#endif
 void B16_CAT(b16_launch_v, B16_VARIANT, _e, B16_EXTRA, _g, B16_GUIDE)(b16::SampleArgs16& a, int blocks, hipStream_t st) {
   hipLaunchKernelGGL((b16::k_sample_bf16<CfgSel, GuideSel, B16_NSLOT, B16_CF, B16_EXTRA, BodySel>), dim3(blocks), dim3(256), 0, st, a);
 }

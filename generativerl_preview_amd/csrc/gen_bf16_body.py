@@ -48,6 +48,7 @@ BSPREAD = int(os.environ.get("GEN_BSPREAD", "2"))  # > 0: bias ds_reads spread, 
 SKEW = int(os.environ.get("GEN_SKEW", "0"))      # > 0: after every ring hand-off wave w idles w * SKEW wait states
 DPOS = int(os.environ.get("GEN_DPOS", "0"))      # where in an MFMA gap an LDS-DMA piece goes: 0 after the gap's fragment read, 1 at the end of the gap (after its VALU work), 2 right after the MFMA
 DMAPOL = os.environ.get("GEN_DMAPOL", "")         # cache-policy bits on the LDS-DMA loads of the weight stream: "", "nt", "sc1", "sc0 sc1" ...
+FOLD = int(os.environ.get("GEN_FOLD", "1"))      # 1: the time-MLP bias of a residual block is folded into its dense2 bias by the packer (b2' = b2 + W2 bt): the T chain starts from 0, no bias read
 ROT = int(os.environ.get("GEN_ROT", "0"))        # 1: one body per wave; wave w issues its LDS-DMA pieces in the gaps = w (mod 4) of each chunk, so that no two waves of the CU issue a piece in the same MFMA gap
 ACC = (0, 32)       # two accumulator buffers of 32 registers
 HB = 64             # 32 fragments x 4
@@ -335,8 +336,12 @@ class Body:
         for n in range(nt):
             t = self.new_tile("h")
             A, Tt = t["buf"], t["buf"] + 16
-            t["bias"] = [(Tt, bt + 32 * n), (A, b1 + 32 * n)]
-            self.chain(self.acc_v(Tt), ste, t, bias=Tt)
+            if FOLD:
+                t["bias"] = [(A, b1 + 32 * n)]
+                self.chain(self.acc_v(Tt), ste, t, zero=True)
+            else:
+                t["bias"] = [(Tt, bt + 32 * n), (A, b1 + 32 * n)]
+                self.chain(self.acc_v(Tt), ste, t, bias=Tt)
             self.chain(self.acc_v(A), in_frags, t, bias=A)
             out = HB + 8 * n
             self.end_tile(t, silu_epilogue(A, "acc", Tt, "v", out), [vq(out), vq(out + 4)])
@@ -769,11 +774,13 @@ CONFIGS = [
 if __name__ == "__main__":
     out = sys.argv[1]
     knobs = dict(LO=DBG_LO, NOP=DBG_NOP, X=",".join(sorted(X)), SPREAD=SPREAD, WAITB=WAITB, BSPREAD=BSPREAD, SKEW=SKEW,
-                 PF=QSLOTS, NSLOT=CONFIGS[0].nslot, CF=CONFIGS[0].cf, ROT=ROT, DPOS=DPOS, DMAPOL=DMAPOL)
-    shipped = dict(LO=2, NOP=0, X="", SPREAD=-1, WAITB=4, BSPREAD=2, SKEW=0, PF=8, NSLOT=4, CF=16, ROT=0, DPOS=0, DMAPOL="")
+                 PF=QSLOTS, NSLOT=CONFIGS[0].nslot, CF=CONFIGS[0].cf, ROT=ROT, DPOS=DPOS, DMAPOL=DMAPOL, FOLD=FOLD)
+    shipped = dict(LO=2, NOP=0, X="", SPREAD=-1, WAITB=4, BSPREAD=2, SKEW=0, PF=8, NSLOT=4, CF=16, ROT=0, DPOS=0, DMAPOL="",
+                   FOLD=1)
     parts = ["// GENERATED by gen_bf16_body.py -- do not edit.  See that file for the design.", "#pragma once",
              "// generator knobs: " + " ".join("%s=%s" % kv for kv in sorted(knobs.items())),
              "#define B16_GEN_DEFAULT_KNOBS %d" % int(knobs == shipped),
+             "#define B16_GEN_FOLD_TIME_BIAS %d" % FOLD,
              "namespace grlhip {", "namespace b16 {", "typedef int i32x4 __attribute__((ext_vector_type(4)));"]
     for cfg in CONFIGS:
         text, cnt, n, b = function_text(cfg)
