@@ -385,7 +385,9 @@ def test_bf16_256_tiles_on_a_three_level_net_without_a_fused_kernel():
 def test_bf16_fused_kernel_at_the_edges_of_its_shape_classes(x_dim, c_dim, guided):
     """Action widths 1 and 16, observation widths around the 16-column k-steps (16, 32, 33, 67), unconditional: the padded
     shape classes of the fused integrator against the oracle.  Seeded (untrained) weights and 8 steps, so states grow:
-    the comparison is relative to max|ref| (2e-2) -- it checks the padding / run-time width plumbing, not the bf16 budget."""
+    the first comparison is relative to max|ref| (2e-2) -- it checks the padding / run-time width plumbing, not the bf16
+    budget; the guided classes are then run again from a start 200 x smaller, which ends at |x| = O(1), against the
+    ABSOLUTE gates."""
     import generativerl_preview_amd as G
     cfg = dict(gl.diffusion_cfg(x_dim, gl.VP, "noise_function", [512, 256, 128], c_dim, energy=guided), device=DEV)
     torch.manual_seed(100 * x_dim + (c_dim or 0))
@@ -415,6 +417,45 @@ def test_bf16_fused_kernel_at_the_edges_of_its_shape_classes(x_dim, c_dim, guide
     m.model.compute_dtype = L.F32
     exact = m.sample(**kw).cpu()
     close(exact, want, tol=TOL, what="fp32 class edge x%d c%s guided %d" % (x_dim, c_dim, guided), rel=True)
+    # the same chain started 200 x smaller ends at |x| = O(1): ABSOLUTE gates for the guided classes too (the unguided
+    # ones have theirs on an ICFM policy, test_bf16_shape_class_edges_absolute_icfm)
+    if guided:
+        kw["x_0"] = (x0 / 200.0).to(DEV)
+        want_s = O.sample_forward_process(sd, cfg, "energy", t_span, x_0=x0 / 200.0, condition=cond, **okw)[-1]
+        assert 0.05 < float(want_s.abs().max()) < 20.0, float(want_s.abs().max())
+        close(m.sample(**kw).cpu(), want_s, tol=TOL, what="fp32 class edge (small start, absolute) x%d c%s" % (x_dim, c_dim))
+        m.model.compute_dtype = L.BF16
+        close(m.sample(**kw).cpu(), want_s, tol=BF16_TOL, what="bf16 class edge (small start, absolute) x%d c%s" % (x_dim, c_dim))
+
+
+@pytest.mark.parametrize("x_dim,c_dim", [(1, 5), (16, 32), (16, 33), (8, 16), (5, 67), (16, None), (1, None), (9, 17)])
+def test_bf16_shape_class_edges_absolute_icfm(x_dim, c_dim):
+    """The same padded shape classes with an ABSOLUTE 2e-2 gate on O(1) actions: an ICFM policy (velocity net, Euler from
+    x_0 ~ N(0, 1)) keeps |x| = O(1) with seeded weights, and it runs the same fused kernel body -- only the per-step
+    coefficient table differs from the VP case above.  Covers x_dim 9 and 16 (> 8: the state's single-rounding path) and
+    1, 5, 8 (hi + lo split)."""
+    import generativerl_preview_amd as G
+    cfg = dict(gl.icfm_cfg(x_dim, [512, 256, 128], c_dim), device=DEV)
+    torch.manual_seed(7 + 100 * x_dim + (c_dim or 0))
+    m = G.IndependentConditionalFlowModel(cfg).to(DEV)
+    m.model.compute_dtype = L.BF16
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    rows = 300
+    gen = torch.Generator().manual_seed(5)
+    x0 = torch.randn(rows, x_dim, generator=gen)
+    cond = torch.randn(rows, c_dim, generator=gen) if c_dim else None
+    t_span = torch.linspace(0.0, 1.0, 21)
+    kw = dict(t_span=t_span, x_0=x0.to(DEV))
+    if c_dim:
+        kw["condition"] = cond.to(DEV)
+    got = m.sample(**kw).cpu()
+    assert "k_sample_bf16" in m.model.plan.fused_kernel(None)
+    want = O.sample_forward_process(sd, cfg, "icfm", t_span, x_0=x0, condition=cond)[-1]
+    assert 0.3 < float(want.abs().max()) < 20.0          # O(1) actions that did move
+    assert float((want - x0).abs().max()) > 0.05
+    close(got, want, tol=BF16_TOL, what="bf16 class edge (icfm, absolute) x%d c%s" % (x_dim, c_dim))
+    m.model.compute_dtype = L.F32
+    close(m.sample(**kw).cpu(), want, tol=TOL, what="fp32 class edge (icfm, absolute) x%d c%s" % (x_dim, c_dim))
 
 
 def test_bf16_full_size_properties():
