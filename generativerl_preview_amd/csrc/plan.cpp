@@ -45,16 +45,17 @@ struct Builder {
     p->linears.push_back(l);
     return (int)p->linears.size() - 1;
   }
-  void linear(std::vector<Op>& prog, int lin, int in, int out, int add, int flags, int pre = -1) {
+  void linear(std::vector<Op>& prog, int lin, int in, int out, int add, int flags, int pre = -1, int z = -1, int zN = 0) {
     const LinearDesc& l = p->linears[lin];
     Op o{};
     o.type = OP_LINEAR; o.K = l.Kpad; o.N = l.N; o.w = (int32_t)l.w_off; o.b = (int32_t)l.b_off;
     o.in = in; o.out = out; o.add = add; o.flags = flags; o.pre = pre; o.lin = lin;
+    o.z = z; o.zN = (flags & F_DSILU) ? (zN > 0 ? zN : l.N) : 0;
     prog.push_back(o);
   }
   void eltwise(std::vector<Op>& prog, int type, int n, int in, int out, int add = -1, int w = 0) {
     Op o{};
-    o.type = type; o.K = 0; o.N = n; o.w = w; o.b = 0; o.in = in; o.out = out; o.add = add; o.lin = -1; o.pre = -1;
+    o.type = type; o.K = 0; o.N = n; o.w = w; o.b = 0; o.in = in; o.out = out; o.add = add; o.lin = -1; o.pre = -1; o.z = -1;
     prog.push_back(o);
   }
 };
@@ -205,35 +206,44 @@ Plan* build_plan(const grlhip_net_desc& d, std::string& err) {
 
       // ---- backward.  gin_mode: 0 = input gradient not needed, 1 = write, 2 = accumulate
       bool ste_written = false;
-      auto bblock = [&](const Blk& k, int gout, int gin, int gin_mode) {
+      // next: the block whose backward follows (its output gradient IS this block's gin): its dz2 = dout SiLU'(z2) comes
+      // out of the epilogue of this block's last GEMM (F_DSILU over the leading next->N features), so it starts with
+      // dz2 already in g_z (dz2_ready) instead of an elementwise pass over dout
+      auto bblock = [&](const Blk& k, int gout, int gin, int gin_mode, const Blk* next, bool dz2_ready) {
         if (k.lm >= 0) {
           dw(k.lm, gout, k.in);
           if (gin_mode) lin_t(k.lm, gout, gin, gin_mode == 2);
-        } else if (gin_mode) {
-          t.eltwise(TB, gin_mode == 2 ? OP_ADD : OP_COPY, k.N, gout, gin);
         }
-        t.eltwise(TB, OP_SILU_BWD, k.N, k.z2, g_z, gout);       // dz2 = dout * silu'(z2)
+        // (identity residual, k.lm < 0: d in += d out rides as the residual operand of the dense1 GEMM below)
+        if (!dz2_ready) t.eltwise(TB, OP_SILU_BWD, k.N, k.z2, g_z, gout);       // dz2 = dout * silu'(z2)
         dw(k.ld, g_z, k.h1);
         // dh1 (= dT) and, from the same epilogue, dz1 = dh1 * silu'(z1) (g_z is this GEMM's input: dz1 -> g_z1)
-        t.linear(TB, T_of(k.ld), g_z, g_h1, k.z1, F_DSILU, g_z1);
+        t.linear(TB, T_of(k.ld), g_z, g_h1, -1, F_DSILU, g_z1, k.z1);
         dw(k.lt, g_h1, ste_t);
         lin_t(k.lt, g_h1, g_ste, ste_written);
         ste_written = true;
         dw(k.l1, g_z1, k.in);
-        if (gin_mode) lin_t(k.l1, g_z1, gin, true);
+        if (gin_mode) {
+          // gin (+)= W1^T dz1 (+ dout for an identity residual); g_z (this block's dz2) is dead by now
+          const int flags = ((k.lm >= 0 || gin_mode == 2) ? F_ACCUM : 0) | (next ? F_DSILU : 0);
+          t.linear(TB, T_of(k.l1), g_z1, gin, k.lm >= 0 ? -1 : gout, flags, next ? g_z : -1, next ? next->z2 : -1, next ? next->N : 0);
+        }
       };
       const int llast = b.by_name["backbone.last_block"];
       dw(llast, p->tr_gout, catf[0]);
       lin_t(llast, p->tr_gout, gcat[0], false);
       int bi = (int)blks.size() - 1;                              // blocks were pushed in forward order
+      bool ready = false;                                          // the first block processed gets dout from last_block
       for (int j = L_ - 2; j >= 0; --j, --bi) {                    // up blocks, reversed
         int i = L_ - 2 - j;
-        bblock(blks[bi], gcat[i], gcat[i + 1], 1);
+        bblock(blks[bi], gcat[i], gcat[i + 1], 1, &blks[bi - 1], ready);
+        ready = true;
       }
-      bblock(blks[bi], gcat[L_ - 1], gcat[L_ - 1] + h[L_ - 1], 2); --bi;   // middle
+      bblock(blks[bi], gcat[L_ - 1], gcat[L_ - 1] + h[L_ - 1], 2, &blks[bi - 1], ready); --bi;   // middle
+      ready = true;
       for (int i = L_ - 2; i >= 0; --i, --bi)                      // down blocks, reversed
-        bblock(blks[bi], gcat[i + 1] + h[i + 1], gcat[i] + h[i], 2);
-      bblock(blks[bi], gcat[0] + h[0], -1, 0);                     // first block (no dx)
+        bblock(blks[bi], gcat[i + 1] + h[i + 1], gcat[i] + h[i], 2, &blks[bi - 1], true);
+      bblock(blks[bi], gcat[0] + h[0], -1, 0, nullptr, true);      // first block (no dx)
       t.eltwise(TB, OP_SILU_BWD, tch, te_t, g_te, g_ste);          // ste = silu(te)
       dw(b.by_name["backbone.sort_t.2"], g_te, a0);
       lin_t(b.by_name["backbone.sort_t.2"], g_te, g_a0, false);
@@ -355,7 +365,7 @@ Plan* build_plan(const grlhip_net_desc& d, std::string& err) {
         if (i) {
           // dz_{i-1} = (W_i^T dz_i) * act'(z_{i-1}) from the GEMM's epilogue; da_{i-1} itself is not stored
           int lt = t.add_matrix(li.K, li.N, li.p_w, -1, 0, li.K, 1);  // W_i^T
-          t.linear(TB, lt, gz[cur], -1, tz[i - 1], F_DSILU | F_NO_OUT | (qnet ? F_RELU_OUT : 0), gz[cur ^ 1]);
+          t.linear(TB, lt, gz[cur], -1, -1, F_DSILU | F_NO_OUT | (qnet ? F_RELU_OUT : 0), gz[cur ^ 1], tz[i - 1]);
           cur ^= 1;
         } else if (!qnet) {
           int lt = t.add_matrix(d.t_dim, li.N, li.p_w, -1, 0, li.K, 1);  // (W_1[:, t_emb cols])^T

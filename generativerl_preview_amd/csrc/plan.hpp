@@ -33,8 +33,9 @@ enum OpType : int32_t {
   OP_HEAD_BWD = 9
 };
 enum OpFlags : int32_t { F_SILU_OUT = 1, F_SAVE_PRE = 2, F_ACCUM = 4, F_RELU_OUT = 8,
-                         // backward: besides out = A in (+bias), pre = out * SiLU'(slab[add]) -- the dZ of the layer below,
-                         // whose pre-activation sits at `add` (nothing is added to out)
+                         // backward: besides out = A in (+bias) (+ slab[add]) (accumulated with F_ACCUM), features
+                         // n < zN of it also give pre[n] = out[n] * SiLU'(slab[z + n]) -- the dZ of the layer below,
+                         // whose pre-activation sits at `z`
                          // (with F_RELU_OUT: ReLU' instead of SiLU'; with F_NO_OUT: out itself is not stored)
                          F_DSILU = 16, F_NO_OUT = 32,
                          // the op only feeds the gradient of the Fourier frequencies: skipped unless Plan::fourier_grad
@@ -43,7 +44,7 @@ enum OpFlags : int32_t { F_SILU_OUT = 1, F_SAVE_PRE = 2, F_ACCUM = 4, F_RELU_OUT
 struct Op {
   int32_t type, K, N, w, b, in, out, add, flags, pre;  // pre: where z (pre-activation) is kept (F_SAVE_PRE)
   int32_t lin;                                         // index into linears (OP_LINEAR), else -1
-  int32_t pad;
+  int32_t z, zN;                                       // F_DSILU: pre-activation offset, number of leading features
 };
 
 struct ParamInfo {
