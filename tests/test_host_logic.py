@@ -111,6 +111,25 @@ def test_workspace_size_follows_the_slab_pitch():
         prev = cur
 
 
+def test_adam_step_validates_its_arguments_without_a_gpu():
+    """grlhip_adam_step: argument checks come before any launch (n <= 0 is a no-op, null buffers and step < 1 are
+    GRLHIP_ERR_INVALID), and grlhip_plan_set_fourier_grad toggles a plan option on the host."""
+    lib = L.lib()
+    assert lib.grlhip_adam_step(None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, None) == 0
+    assert lib.grlhip_adam_step(None, None, None, None, 16, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, None) != 0
+    assert b"null" in lib.grlhip_last_error()
+    buf = (ctypes.c_float * 16)()
+    ptr = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.grlhip_adam_step(ptr, ptr, ptr, ptr, 16, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, None) != 0
+    assert b"step" in lib.grlhip_last_error()
+    from generativerl_preview_amd.engine import NetPlan
+    plan = NetPlan(L.NET_RESNET, 6, 6, 17, 32, 32, 128, [64, 32, 16])
+    assert plan.fourier_grad is True
+    plan.set_fourier_grad(False)
+    assert plan.fourier_grad is False
+    assert lib.grlhip_plan_set_fourier_grad(None, 1) != 0
+
+
 def test_plan_rejects_bad_wiring():
     from generativerl_preview_amd.engine import NetPlan
     with pytest.raises(L.GrlHipError, match="hidden"):
