@@ -47,3 +47,34 @@ def test_gpu_flat_adam_matches_torch_adam(weight_decay):
     assert {k: tuple(v.shape) for k, v in a.state_dict().items()} == {k: tuple(v.shape) for k, v in b.state_dict().items()}
     sd = opt.state_dict()
     assert sd["step"] == 4 and float(sd["exp_avg"].abs().max()) > 0
+
+
+@pytest.mark.gpu
+def test_gpu_flat_adam_on_a_q_network():
+    """FlatAdam over a QNetwork (ReLU ConcatenateMLP, no frozen parameters): regression of Q(a, s) onto a target through
+    the differentiable HIP forward, against torch.optim.Adam on a twin; the packed-weight cache of the owner is dropped
+    after every step (the parameters changed behind torch's version counters)."""
+    from generativerl_preview_amd.optim import FlatAdam
+    from generativerl_preview_amd.rl_modules.value_network.q_network import QNetwork
+    cfg = dict(backbone=dict(type="ConcatenateMLP", args=dict(hidden_sizes=[3 + 5, 64, 32], output_size=1, activation="relu")))
+    torch.manual_seed(11)
+    a = QNetwork(cfg).to(DEV)
+    b = QNetwork(cfg).to(DEV)
+    b.load_state_dict(copy.deepcopy(a.state_dict()))
+    gen = torch.Generator().manual_seed(2)
+    act, st, tgt = torch.randn(500, 3, generator=gen).to(DEV), torch.randn(500, 5, generator=gen).to(DEV), torch.randn(500, 1, generator=gen).to(DEV)
+    b(act, st)                                     # plans the twin (FlatAdam needs the plan's parameter order)
+    ref = torch.optim.Adam(a.parameters(), lr=1e-2)
+    opt = FlatAdam(b, lr=1e-2)
+    for _ in range(5):
+        ref.zero_grad()
+        la = (a(act, st) - tgt).pow(2).mean()
+        la.backward()
+        ref.step()
+        opt.zero_grad()
+        lb = (b(act, st) - tgt).pow(2).mean()
+        lb.backward()
+        opt.step()
+        assert abs(float(la) - float(lb)) <= 2e-5 * abs(float(la)), (float(la), float(lb))
+    for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert float((p - q).abs().max()) <= 5e-5 * (float(p.abs().max()) + 1e-12), k
