@@ -87,7 +87,8 @@ int grlhip_plan_param_info(const grlhip_plan* plan, int index, char* name_buf, s
 /* Replaces: the `requires_grad` argument of GaussianFourierProjectionTimeEncoder (grl/neural_network/encoders.py:53-66;
  * False by default and in every shipped configuration): with enable == 0 the training entry points
  * (grlhip_loss_fwd_bwd, grlhip_cep_loss_fwd_bwd, grlhip_net_backward, grlhip_sample_*_backward) leave the gradient slot
- * of "t_encoder.W" untouched and skip the work that only feeds it.  Default: enabled. */
+ * of "t_encoder.W" untouched and skip the work that only feeds it.  Default: enabled.  The one mutable property of a
+ * plan: do not change it while a call on the same plan is in progress on another thread. */
 int grlhip_plan_set_fourier_grad(grlhip_plan* plan, int enable);
 
 /* Introspection (no counterpart in the reference; used by the tests and to size stream captures): the number of
