@@ -393,9 +393,12 @@ int grlhip_sample_fixed(const grlhip_plan* plan, const void* packed, int dtype, 
 int grlhip_bf16_fused_kernel(const grlhip_plan* plan, const grlhip_plan* guidance, char* name_buf, size_t name_buf_len) {
   if (!plan || !plan->p) return fail(GRLHIP_ERR_INVALID, "null plan");
   const Plan* g = guidance ? guidance->p : nullptr;
-  const char* nm = bf16_fused_ok(plan->p) ? bf16_kernel_name(plan->p, g) : "";
+  const bool fused = bf16_fused_ok(plan->p);
+  const char* nm = fused ? bf16_kernel_name(plan->p, g)
+                   : (!g && wide_ok(plan->p)) ? "layer engine: k_w_gemm (row-major bf16 activations; Euler / Euler-Maruyama calls)"
+                                              : "layer engine: k_bt_gemm_bf16 (batch engine, fp32 activations)";
   if (name_buf && name_buf_len) snprintf(name_buf, name_buf_len, "%s", nm);
-  return nm[0] ? 1 : 0;
+  return fused && nm[0] ? 1 : 0;
 }
 
 // ---- allocation-free variant of grlhip_sample_ode (include/grlhip.h): the fused bf16 integrator with its

@@ -78,11 +78,20 @@ class NetPlan:
     def fused_kernel(self, guidance=None):
         """Name of the persistent fused bf16 integrator that GRLHIP_BF16 sampling of this plan (energy-guided by the
         plan `guidance`) runs, or "" when it runs layer by layer on the batch engine (grlhip_bf16_fused_kernel)."""
-        buf = ctypes.create_string_buffer(160)
-        rc = L.lib().grlhip_bf16_fused_kernel(self.handle, guidance.handle if guidance is not None else None, buf, 160)
+        rc, text = self._bf16_kernel(guidance)
+        return text if rc == 1 else ""
+
+    def bf16_engine(self, guidance=None):
+        """What GRLHIP_BF16 sampling of this plan runs: the fused integrator's kernel class, or the layer engine
+        ("layer engine: k_w_gemm ..." for wide nets, "layer engine: k_bt_gemm_bf16 ..." otherwise)."""
+        return self._bf16_kernel(guidance)[1]
+
+    def _bf16_kernel(self, guidance):
+        buf = ctypes.create_string_buffer(200)
+        rc = L.lib().grlhip_bf16_fused_kernel(self.handle, guidance.handle if guidance is not None else None, buf, 200)
         if rc < 0:
             L.check(rc)
-        return buf.value.decode()
+        return rc, buf.value.decode()
 
     def packed_bytes(self, dtype=L.F32):
         return L.lib().grlhip_packed_bytes(self.handle, dtype)

@@ -100,8 +100,9 @@ int grlhip_plan_program_info(const grlhip_plan* plan, int program, int32_t* n_op
 /* Introspection (no counterpart in the reference): 1 when GRLHIP_BF16 sampling of `plan` (energy-guided by
  * `guidance`, may be NULL) runs the persistent fused integrator k_sample_bf16 -- any conditional or unconditional
  * [512,256,128] TemporalSpatialResidualNet with at most 16 state features (guided: at most 32 condition features and
- * a [256,256] energy net) -- and 0 when it runs layer by layer on the batch engine.  name_buf (optional) receives
- * the kernel class. */
+ * a [256,256] energy net) -- and 0 when it runs layer by layer.  name_buf (optional) receives the kernel class; for
+ * layer-by-layer plans the engine: the row-major bf16 engine of wide nets (k_w_gemm: a hidden width >= 256, all widths
+ * multiples of 8, unguided Euler / Euler-Maruyama calls) or the batch engine (k_bt_gemm_bf16). */
 int grlhip_bf16_fused_kernel(const grlhip_plan* plan, const grlhip_plan* guidance, char* name_buf, size_t name_buf_len);
 
 /* Bytes of the packed weight image for `dtype` (the image layout is private to the library and differs

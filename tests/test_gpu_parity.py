@@ -316,10 +316,12 @@ def test_bf16_guided_ode_vs_oracle(name, rows, steps, scale):
 @pytest.mark.parametrize("name,rows,steps", [("small_vp_noise", 333, 20), ("gvp_wide", 300, 20), ("small_uncond_noise", 130, 50),
                                              ("small_icfm", 257, 20)])
 def test_bf16_generic_shapes_run_on_the_batch_engine(name, rows, steps):
-    """Shapes without a fused bf16 kernel (C5's [1024] net, the small nets): GRLHIP_BF16 runs the batch engine
-    with bf16 MFMAs (fp32 activations in HBM, bf16 operands, fp32 accumulate) -- same 2e-2 tolerance."""
+    """Shapes without a fused bf16 kernel run layer by layer: C5's [1024] net on the row-major bf16 engine of the wide
+    nets (k_w_gemm: bf16 activations in HBM), the small nets on the batch engine with bf16 MFMAs (fp32 activations in
+    HBM, bf16 operands, fp32 accumulate) -- same 2e-2 tolerance."""
     kind, cfg, m, sd = _bf16_model(name)
     assert m.model.plan.fused_kernel() == ""
+    assert ("k_w_gemm" if name == "gvp_wide" else "k_bt_gemm_bf16") in m.model.plan.bf16_engine()
     S = gu.cond_dim(cfg)
     D = cfg["x_size"]
     gen = torch.Generator().manual_seed(17)
@@ -331,19 +333,20 @@ def test_bf16_generic_shapes_run_on_the_batch_engine(name, rows, steps):
         kw["condition"] = cond.to(DEV)
     got = m.sample(**kw).cpu()
     want = O.sample_forward_process(sd, cfg, kind, t_span, x_0=x0, condition=cond)[-1]
-    close(got, want, tol=BF16_TOL, what="bf16 batch engine %s" % name)
+    close(got, want, tol=BF16_TOL, what="bf16 layer engine %s" % name)
     m.model.compute_dtype = L.F32
     exact = m.sample(**kw).cpu()
     assert float((got - exact).abs().max()) > 0.0, "bf16 path returned the fp32 result bit for bit: not the bf16 kernels"
 
 
 def test_bf16_wide_layers_256_tiles_match_the_128_tiles_bit_for_bit():
-    """C5's [1024] net at 65 536 rows: its 1024-wide layers run k_bt_gemm_bf16_big (256 x 256 tiles, chosen when the
-    grid fills the chip twice over); at 1 024 rows the same layers run the 128 x 128 kernel.  Same bf16 fragments, same
-    k order, rows are independent: the first 1 024 rows of the big batch must equal the small batch BIT FOR BIT, and the
-    small batch is the one the oracle test above covers.  Also a ragged row count (65 536 + 300: slabs of more than
-    32 768 rows are padded to a multiple of 256, so this one runs the 256-tile kernel too)."""
+    """C5's [1024] net on the wide engine (k_w_gemm, persistent 256 x 256 tiles) at 65 536, 1 024 and 65 836 rows: rows
+    are independent and the k order of a row does not depend on the batch, so the first 1 024 rows of the big batch must
+    equal the small batch BIT FOR BIT (the small batch is the one the oracle test above covers), and a ragged row count
+    (padded to whole 256-row tiles) must agree with the big batch on the rows they share.  (Written in round 2 for the
+    batch engine's 256-tile against its 128-tile kernel; that pair is exercised by the three-level net below.)"""
     kind, cfg, m, sd = _bf16_model("gvp_wide")
+    assert "k_w_gemm" in m.model.plan.bf16_engine()
     gen = torch.Generator().manual_seed(23)
     rows = 65536 + 300
     x0 = torch.randn(rows, cfg["x_size"], generator=gen).to(DEV)
@@ -355,7 +358,7 @@ def test_bf16_wide_layers_256_tiles_match_the_128_tiles_bit_for_bit():
     assert torch.equal(big[:1024], small)
     assert torch.equal(ragged[:65536], big)
     want = O.sample_forward_process(sd, cfg, kind, t_span, x_0=x0[65536 - 64:65536 + 64].cpu())[-1]
-    close(ragged[65536 - 64:65536 + 64].cpu(), want, tol=BF16_TOL, what="bf16 256-tile kernel, rows around 65536")
+    close(ragged[65536 - 64:65536 + 64].cpu(), want, tol=BF16_TOL, what="bf16 wide engine, rows around 65536")
 
 
 def test_bf16_256_tiles_on_a_three_level_net_without_a_fused_kernel():
@@ -367,7 +370,7 @@ def test_bf16_256_tiles_on_a_three_level_net_without_a_fused_kernel():
     torch.manual_seed(20)
     m = G.DiffusionModel(cfg).to(DEV)
     m.model.compute_dtype = L.BF16
-    assert m.model.plan.fused_kernel() == ""
+    assert m.model.plan.fused_kernel() == "" and "k_bt_gemm_bf16" in m.model.plan.bf16_engine()
     gen = torch.Generator().manual_seed(24)
     rows = 140000
     x0 = torch.randn(rows, 20, generator=gen).to(DEV)
