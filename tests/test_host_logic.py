@@ -130,6 +130,21 @@ def test_adam_step_validates_its_arguments_without_a_gpu():
     assert lib.grlhip_plan_set_fourier_grad(None, 1) != 0
 
 
+def test_stage_backward_rejects_bad_arguments_without_a_gpu():
+    """grlhip_sample_stages_backward / grlhip_sample_ode_backward: the checks that need no device (null plan or weight
+    image, wrong plan kind) return an error code and a message instead of launching anything."""
+    lib = L.lib()
+    from generativerl_preview_amd.engine import NetPlan
+    buf = (ctypes.c_float * 64)()
+    ptr = ctypes.cast(buf, ctypes.c_void_p)
+    for fn in (lib.grlhip_sample_stages_backward, lib.grlhip_sample_ode_backward):
+        assert fn(None, ptr, L.F32, ptr, None, ptr, 1, 4, ptr, None, ptr, ptr, 64, None) != 0
+        assert b"null plan" in lib.grlhip_last_error()
+        plan = NetPlan(L.NET_RESNET, 6, 6, 0, 32, 0, 0, [64, 32, 16])
+        assert fn(plan.handle, None, L.F32, ptr, None, ptr, 1, 4, ptr, None, ptr, ptr, 64, None) != 0
+        assert b"packed" in lib.grlhip_last_error()
+
+
 def test_plan_rejects_bad_wiring():
     from generativerl_preview_amd.engine import NetPlan
     with pytest.raises(L.GrlHipError, match="hidden"):

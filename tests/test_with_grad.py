@@ -133,6 +133,31 @@ def test_gpu_dpm_solver_with_grad_vs_oracle_autograd(name, order, typ, solver_ty
 
 
 @pytest.mark.gpu
+def test_gpu_stage_backward_rejects_what_it_does_not_implement():
+    """grlhip_sample_stages_backward is fp32 only and needs a RESNET plan with out_dim == x_dim; a workspace that is too
+    small is refused with the needed size in the message."""
+    from generativerl_preview_amd import _lib as L
+    kind, cfg, m = um.build("small_vp_noise", DEV)
+    plan = m.model.plan
+    packed = m.model.packed(L.F32)
+    states = torch.zeros(3, 8, 6, device=DEV)
+    table = torch.zeros(2, L.COEF_STRIDE, device=DEV)
+    flat = torch.zeros(L.lib().grlhip_grad_numel(plan.handle), device=DEV)
+    cond = torch.zeros(8, 17, device=DEV)
+    ws = torch.empty(256, dtype=torch.uint8, device=DEV)
+    args = lambda dtype, w: (plan.handle, packed.data_ptr(), dtype, states.data_ptr(), cond.data_ptr(), table.data_ptr(), 2, 8,  # noqa: E731
+                             states.data_ptr(), None, flat.data_ptr(), w.data_ptr(), w.numel(), None)
+    assert L.lib().grlhip_sample_stages_backward(*args(L.BF16, ws)) == -2   # GRLHIP_ERR_UNSUPPORTED
+    assert L.lib().grlhip_sample_stages_backward(*args(L.F32, ws)) == -4     # GRLHIP_ERR_WORKSPACE
+    assert b"need" in L.lib().grlhip_last_error()
+    _, _, e = um.build("small_energy", DEV)
+    gplan = e.energy_guidance.model.plan      # a CONCAT_MLP plan
+    assert L.lib().grlhip_sample_stages_backward(gplan.handle, e.energy_guidance.model.packed(L.F32).data_ptr(), L.F32, states.data_ptr(),
+                                                 cond.data_ptr(), table.data_ptr(), 2, 8, states.data_ptr(), None, flat.data_ptr(),
+                                                 ws.data_ptr(), ws.numel(), None) == -1   # GRLHIP_ERR_INVALID
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("rows", [90, 65536 + 40])
 def test_gpu_dpm_solver_trajectory_with_grad(rows):
     """A loss on the final AND an intermediate solver state (sample_forward_process, with_grad=True), order 3: the
