@@ -179,6 +179,13 @@ int grlhip_plan_set_fourier_grad(grlhip_plan* plan, int enable) {
   return 0;
 }
 
+int grlhip_plan_set_backward_split(grlhip_plan* plan, int pieces) {
+  if (!plan || !plan->p) return fail(GRLHIP_ERR_INVALID, "null plan");
+  if (pieces != 2 && pieces != 3) return fail(GRLHIP_ERR_INVALID, "backward split: 2 or 3 bf16 pieces per fp32 value");
+  plan->p->bwd_pieces = pieces;
+  return 0;
+}
+
 int64_t grlhip_grad_numel(const grlhip_plan* plan) { return plan && plan->p ? plan->p->grad_numel : 0; }
 int64_t grlhip_grad_offset(const grlhip_plan* plan, int index) {
   if (!plan || !plan->p || index < 0 || index >= (int)plan->p->params.size()) return -1;

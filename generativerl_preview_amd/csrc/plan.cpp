@@ -231,9 +231,11 @@ Plan* build_plan(const grlhip_net_desc& d, std::string& err) {
       };
       const int llast = b.by_name["backbone.last_block"];
       dw(llast, p->tr_gout, catf[0]);
-      lin_t(llast, p->tr_gout, gcat[0], false);
+      // d cat[0] = W_last^T dout; the leading h[0] features are the output gradient of the block processed first, whose
+      // dz2 = dout SiLU'(z2) comes out of the same epilogue (as between blocks, see bblock)
+      t.linear(TB, T_of(llast), p->tr_gout, gcat[0], -1, F_DSILU, g_z, blks.back().z2, blks.back().N);
       int bi = (int)blks.size() - 1;                              // blocks were pushed in forward order
-      bool ready = false;                                          // the first block processed gets dout from last_block
+      bool ready = true;
       for (int j = L_ - 2; j >= 0; --j, --bi) {                    // up blocks, reversed
         int i = L_ - 2 - j;
         bblock(blks[bi], gcat[i], gcat[i + 1], 1, &blks[bi - 1], ready);

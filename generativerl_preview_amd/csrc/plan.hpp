@@ -76,6 +76,7 @@ struct Plan {
   int32_t tr_gx = -1;            // d loss / d x (RESNET; written by the last train_bwd_dx_ops ops of train_bwd)
   int32_t train_bwd_dx_ops = 0;  // trailing ops of train_bwd that only the differentiable integrator needs
   bool fourier_grad = true;      // compute d loss / d (Fourier frequencies) in the training entry points
+  int32_t bwd_pieces = 3;        // bf16 pieces per fp32 value in the GEMMs of the training-backward program (3 or 2)
   void* d_train_fwd = nullptr;
   void* d_train_bwd = nullptr;
   int32_t slab_features = 0;

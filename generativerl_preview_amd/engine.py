@@ -53,6 +53,7 @@ class NetPlan:
         self.handle = h
         self._ws = {}
         self.fourier_grad = True     # the library's default (grlhip_plan_set_fourier_grad)
+        self.backward_split = 3      # the library's default (grlhip_plan_set_backward_split)
         n = L.lib().grlhip_plan_num_params(h)
         self.params = []
         buf = ctypes.create_string_buffer(256)
@@ -66,6 +67,12 @@ class NetPlan:
         if enable != self.fourier_grad:
             L.check(L.lib().grlhip_plan_set_fourier_grad(self.handle, int(enable)))
             self.fourier_grad = enable
+
+    def set_backward_split(self, pieces):
+        """bf16 pieces per fp32 value in the GEMMs of the backward programs: 3 (default, fp32 rounding level) or 2
+        (three MFMAs per product instead of six: gradients carry ~1e-5 relative error per product)."""
+        L.check(L.lib().grlhip_plan_set_backward_split(self.handle, int(pieces)))
+        self.backward_split = int(pieces)
 
     def __del__(self):
         try:

@@ -29,6 +29,7 @@ class IntrinsicModel(nn.Module):
                 self.model[enc] = nn.Identity()
         self.model["backbone"] = get_module(config.backbone.type)(**config.backbone.args)
         self.compute_dtype = L.F32
+        self.backward_split = 3      # bf16 pieces per fp32 value in the backward GEMMs (NetPlan.set_backward_split)
         self._plan = None
         self._packed = {}
 
@@ -80,6 +81,8 @@ class IntrinsicModel(nn.Module):
         # the Fourier frequencies are frozen unless the encoder was built with requires_grad=True (encoders.py:53-66):
         # the training entry points then skip the work that only feeds their gradient
         self._plan.set_fourier_grad(bool(self.model["t_encoder"].W.requires_grad))
+        if self._plan.backward_split != getattr(self, "backward_split", 3):
+            self._plan.set_backward_split(getattr(self, "backward_split", 3))
         return self._plan
 
     def set_io_dims(self, x_dim, cond_dim):

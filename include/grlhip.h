@@ -91,6 +91,15 @@ int grlhip_plan_param_info(const grlhip_plan* plan, int index, char* name_buf, s
  * plan: do not change it while a call on the same plan is in progress on another thread. */
 int grlhip_plan_set_fourier_grad(grlhip_plan* plan, int enable);
 
+/* No counterpart in the reference (its GPU matmuls are whatever precision torch is configured for).  The fp32 engine
+ * forms every fp32 product from bf16 pieces on the matrix cores: three pieces per value, six MFMAs per product = fp32
+ * rounding level.  pieces == 2 (three MFMAs per product, |error| <= ~2^-16 of each product,
+ * random sign) applies to the GEMMs of the BACKWARD programs only -- weight gradients and input gradients of
+ * grlhip_loss_fwd_bwd, grlhip_cep_loss_fwd_bwd, grlhip_net_backward, grlhip_sample_*_backward; forwards, losses and
+ * sampling are not affected.  Gradients stay bit-reproducible.  Default 3.  Change it only while no call on the plan
+ * is in progress. */
+int grlhip_plan_set_backward_split(grlhip_plan* plan, int pieces);
+
 /* Introspection (no counterpart in the reference; used by the tests and to size stream captures): the number of
  * ops of one of the plan's programs (0 forward, 1 energy forward + input gradient, 2 training forward,
  * 3 training backward) and the number of kernel launches the batch engine turns it into per pass (a plain

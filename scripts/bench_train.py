@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="rows per GPU")
+    ap.add_argument("--backward-split", type=int, default=3, choices=(2, 3),
+                    help="bf16 pieces per fp32 value in the backward GEMMs (3 = fp32 rounding level, the default)")
     args = ap.parse_args()
     from generativerl_preview_amd import launch
     if launch.needs_self_launch(args.gpus):   # nothing has touched the GPU yet
@@ -42,6 +44,7 @@ def main():
     from generativerl_preview_amd.distributed import attach_flat_grads
     torch.manual_seed(0)  # identical initial weights on every rank
     m = G.IndependentConditionalFlowModel(dict(gl.icfm_cfg(6, [512, 256, 128], 17), device=device)).to(device)
+    m.model.backward_split = args.backward_split
     fg = attach_flat_grads(m.model)   # .grad of every parameter is a view of ONE flat buffer
     from generativerl_preview_amd.optim import FlatAdam
     opt = FlatAdam(m.model, lr=1e-4)   # ONE launch over the flat parameter buffer (grlhip_adam_step)
@@ -75,7 +78,7 @@ def main():
             "metric": "training rows/sec (ICFM flow_matching_loss fwd+bwd+all-reduce+Adam)",
             "value": B * world * args.steps / elapsed, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic", "backward_split": args.backward_split,
             "config": {"workload": "C3 GMPO ICFM training step, batch %d per GPU, net [512,256,128], obs 17 / act 6, sigma 0.1" % B,
                        "parallelism": "data parallel x%d, one flat fp32 all-reduce per step" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",

@@ -635,6 +635,47 @@ def test_gradients_are_bit_reproducible():
         assert torch.equal(runs[0][k], runs[1][k]), "gradient of %s differs between two identical passes" % k
 
 
+def test_two_piece_backward_split_is_opt_in_close_and_reproducible():
+    """grlhip_plan_set_backward_split(2): the backward GEMMs form each fp32 product from two bf16 pieces per value (three
+    MFMAs) instead of three (six).  Default stays 3; the loss (forward) is untouched bit for bit; the gradients move by
+    ~1e-5 of their norm, stay inside the golden gate on the reference's vectors, and stay bit-reproducible."""
+    name = "icfm_cond"
+    kind, cfg, m = um.build(name, DEV)
+    assert m.model.plan.backward_split == 3
+    gen = torch.Generator().manual_seed(11)
+    B = 20000
+    x0, x1 = torch.randn(B, 6, generator=gen).to(DEV), torch.rand(B, 6, generator=gen).to(DEV)
+    cond, t, eps = torch.randn(B, 17, generator=gen).to(DEV), torch.rand(B, generator=gen).to(DEV), torch.randn(B, 6, generator=gen).to(DEV)
+
+    def grads():
+        m.zero_grad(set_to_none=True)
+        loss = m.flow_matching_loss(x0, x1, cond, t=t, noise=eps)
+        loss.backward()
+        return loss.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    l3, g3 = grads()
+    m.model.backward_split = 2
+    l2, g2 = grads()
+    assert m.model.plan.backward_split == 2
+    l2b, g2b = grads()
+    assert torch.equal(l3, l2) and torch.equal(l2, l2b)
+    differs = 0
+    for k in g3:
+        assert torch.equal(g2[k], g2b[k]), "two-piece gradient of %s differs between two identical passes" % k
+        err = float((g2[k] - g3[k]).double().norm() / g3[k].double().norm().clamp_min(1e-30))
+        assert err <= 1e-4, (k, err)
+        differs += int(not torch.equal(g2[k], g3[k]))
+    assert differs > 10, "the option changed nothing: is the two-piece kernel running?"
+    g = gu.load("model_%s.npz" % name)
+    m.zero_grad(set_to_none=True)
+    m.flow_matching_loss(cu(g["eps"]), cu(g["x"]), cu(g.get("cond")), t=cu(g["fm_t"]), noise=cu(g["fm_eps"])).backward()
+    _check_grads(m, g, "fm")
+    m.model.backward_split = 3
+    l3b, g3b = grads()
+    assert all(torch.equal(g3[k], g3b[k]) for k in g3)
+    with pytest.raises(L.GrlHipError):
+        m.model.plan.set_backward_split(4)
+
+
 def test_training_batch_spanning_two_chunks_vs_oracle():
     """The batch engine walks the rows in chunks of 65 536: per-row losses and every gradient of a batch
     that crosses the boundary (and is not a multiple of the 128-row tile) against torch autograd on the oracle."""
