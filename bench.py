@@ -256,6 +256,13 @@ def c3_training(ranks, dry=False, steps=20, warmup=5):
 
     elapsed, loss = ranks.timed(train_step, warmup, steps)
     assert bool(torch.isfinite(loss))
+    dt2 = None
+    if not dry:   # the opt-in two-piece backward, reported beside the default and never instead of it
+        m3.model.backward_split = 2
+        elapsed2, loss2 = ranks.timed(train_step, 2, steps)
+        m3.model.backward_split = 3
+        assert bool(torch.isfinite(loss2))
+        dt2 = elapsed2 / steps
     if rank != 0:
         return None
     dt = elapsed / steps
@@ -271,6 +278,11 @@ def c3_training(ranks, dry=False, steps=20, warmup=5):
                                     "expected": sum(n * (r + 1.0) for r, n in enumerate(rows)) / sum(rows)}
         return entry
     entry["roofline"] = f32_roofline(B * 9759936 / dt / 1e12)   # per GPU, whole step over wall time
+    entry["backward_split"] = 3
+    entry["two_piece_backward"] = {
+        "ms_per_step": dt2 * 1e3, "value": B * world / dt2, "unit": "rows/s",
+        "note": "the same step with grlhip_plan_set_backward_split(plan, 2): two bf16 pieces per fp32 value (three MFMAs "
+                "per product) in the backward GEMMs only; loss unchanged, gradients ~1e-5 relative (opt-in, not the default)"}
     if world == 1:
         try:   # the same step on the host cores through the oracle (bounded sample)
             from oracle import grl_oracle as O
