@@ -72,6 +72,8 @@ PROTOTYPES = {
                                                   _vp, _sz, _vp]),
     "grlhip_adam_step": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                         ctypes.c_float, ctypes.c_float, _i64, _vp]),
+    "grlhip_adam_step_counted": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                                ctypes.c_float, ctypes.c_float, _vp, ctypes.c_int, _vp]),
     "grlhip_cep_loss_fwd_bwd": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp,
                                                _i64, _vp, _sz, _vp]),
 }

@@ -69,8 +69,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct AdamArgs {
   float* p; const float* g; float* m; float* v; int64_t n;
   float b1, b2, eps, wd, step_size, bc2_sqrt;
+  const float* coef;   // null, or {step_size, bc2_sqrt} on the device (grlhip_adam_step_counted: the step count lives there)
 };
+// the device-resident step record of grlhip_adam_step_counted: one thread advances it and derives the bias corrections
+// (in double, as the host does for grlhip_adam_step)
+struct AdamRecord { long long step; float step_size, bc2_sqrt; };
+__global__ void k_adam_tick(AdamRecord* r, float lr, float b1, float b2) {
+  const long long t = r->step + 1;
+  r->step = t;
+  r->step_size = (float)((double)lr / (1.0 - pow((double)b1, (double)t)));
+  r->bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)t));
+}
 __global__ __launch_bounds__(256) void k_adam_step(AdamArgs a) {
+  if (a.coef) { a.step_size = a.coef[0]; a.bc2_sqrt = a.coef[1]; }
   auto one = [&](int64_t i) {
     float g = a.g[i];
     const float p = a.p[i];
@@ -597,9 +608,24 @@ int grlhip_adam_step(float* params, const float* grads, float* exp_avg, float* e
   if (step < 1) return fail(GRLHIP_ERR_INVALID, "adam_step: step counts from 1");
   // bias corrections in double on the host, as torch.optim.Adam computes them for a Python-float step
   const double bc1 = 1.0 - std::pow((double)beta1, (double)step), bc2 = 1.0 - std::pow((double)beta2, (double)step);
-  AdamArgs a{params, grads, exp_avg, exp_avg_sq, n, beta1, beta2, eps, weight_decay, (float)(lr / bc1), (float)std::sqrt(bc2)};
+  AdamArgs a{params, grads, exp_avg, exp_avg_sq, n, beta1, beta2, eps, weight_decay, (float)(lr / bc1), (float)std::sqrt(bc2), nullptr};
   const int64_t blocks = std::min<int64_t>((n + 1023) / 1024, 4096);
   hipLaunchKernelGGL(k_adam_step, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int grlhip_adam_step_counted(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, void* step_record, int advance,
+                             void* stream) {
+  if (!step_record || ((size_t)step_record & 7)) return fail(GRLHIP_ERR_INVALID, "adam_step_counted: step_record must be an 8-byte aligned device pointer to 16 bytes");
+  if (advance) hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, (hipStream_t)stream, (AdamRecord*)step_record, lr, beta1, beta2);
+  if (n > 0) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq) return fail(GRLHIP_ERR_INVALID, "null params/grads/exp_avg/exp_avg_sq");
+    AdamArgs a{params, grads, exp_avg, exp_avg_sq, n, beta1, beta2, eps, weight_decay, 0.f, 1.f, &((const AdamRecord*)step_record)->step_size};
+    const int64_t blocks = std::min<int64_t>((n + 1023) / 1024, 4096);
+    hipLaunchKernelGGL(k_adam_step, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  }
   HIP_TRY(hipGetLastError());
   return 0;
 }

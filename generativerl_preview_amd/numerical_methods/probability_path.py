@@ -137,4 +137,5 @@ class ConditionalProbabilityPath:
         self.config = as_config(config)
 
     def std(self, t):
-        return torch.tensor(self.config.sigma, device=t.device)
+        # (a fill, not a host-to-device copy: the training step stays capturable into a HIP graph)
+        return torch.full((), float(self.config.sigma), device=t.device)

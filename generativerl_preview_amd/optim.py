@@ -6,7 +6,11 @@ single launch instead of the per-tensor kernels of the foreach implementation.
 parameters are moved into ONE flat fp32 buffer in the library's gradient layout (their ``.data`` become views of it, so
 ``state_dict()``, ``named_parameters()`` and the weight packing see ordinary tensors) and their ``.grad`` are the views
 of the FlatGrads buffer the fused losses accumulate into.  ``step()`` is one kernel over the trainable range(s);
-``zero_grad()`` one memset.  Same update rule and defaults as ``torch.optim.Adam`` (amsgrad / maximize off)."""
+``zero_grad()`` one memset.  Same update rule and defaults as ``torch.optim.Adam`` (amsgrad / maximize off).
+
+``capturable=True`` keeps the step count on the device (grlhip_adam_step_counted), as ``torch.optim.Adam(capturable=True)``
+does: a whole training step -- loss forward + backward, gradient all-reduce, ``step()`` -- can then be captured once with
+``torch.cuda.graph`` and replayed (``tests/test_optim.py``)."""
 import torch
 
 from . import _lib as L
@@ -14,15 +18,18 @@ from .distributed import attach_flat_grads
 
 
 class FlatAdam:
-    def __init__(self, owner, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, owner, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, capturable=False):
         if lr < 0.0 or eps < 0.0 or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0 or weight_decay < 0.0:
             raise ValueError("invalid Adam hyper-parameters")
         self.owner = owner
         self.fg = attach_flat_grads(owner)
         self.defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
         self.param_groups = [dict(self.defaults, params=[p for p, _, _ in self.fg.slices if p.requires_grad])]
-        self.step_count = 0
+        self._steps = 0
+        self.capturable = bool(capturable)
         dev = self.fg.flat.device
+        # capturable: {int64 step; float step_size; float bc2_sqrt} on the device, advanced by the library
+        self.step_record = torch.zeros(2, dtype=torch.int64, device=dev) if capturable else None
         n = self.fg.n
         self.flat_params = torch.zeros(n, dtype=torch.float32, device=dev)
         with torch.no_grad():
@@ -49,6 +56,18 @@ class FlatAdam:
                 raise RuntimeError("a parameter no longer lives in FlatAdam's buffer (module moved or re-assigned): "
                                    "build a new FlatAdam")
 
+    @property
+    def step_count(self):
+        return int(self.step_record[0].item()) if self.capturable else self._steps
+
+    @step_count.setter
+    def step_count(self, value):
+        if self.capturable:
+            self.step_record.zero_()
+            self.step_record[0] = int(value)
+        else:
+            self._steps = int(value)
+
     def zero_grad(self, set_to_none=False):
         self.fg.ensure()
         self.fg.zero()
@@ -57,16 +76,20 @@ class FlatAdam:
     def step(self):
         self._check_views()
         self.fg.ensure()
-        self.step_count += 1
         g = self.param_groups[0]
         dev = self.flat_params.device
+        if not self.capturable:
+            self._steps += 1
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            for lo, hi in self.ranges:
-                L.check(L.lib().grlhip_adam_step(self.flat_params.data_ptr() + 4 * lo, self.fg.flat.data_ptr() + 4 * lo,
-                                                 self.exp_avg.data_ptr() + 4 * lo, self.exp_avg_sq.data_ptr() + 4 * lo,
-                                                 hi - lo, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
-                                                 g["weight_decay"], self.step_count, stream))
+            for i, (lo, hi) in enumerate(self.ranges):
+                ptrs = (self.flat_params.data_ptr() + 4 * lo, self.fg.flat.data_ptr() + 4 * lo,
+                        self.exp_avg.data_ptr() + 4 * lo, self.exp_avg_sq.data_ptr() + 4 * lo, hi - lo,
+                        g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"])
+                if self.capturable:   # the step count lives on the device: nothing per-step is frozen into a captured graph
+                    L.check(L.lib().grlhip_adam_step_counted(*ptrs, self.step_record.data_ptr(), int(i == 0), stream))
+                else:
+                    L.check(L.lib().grlhip_adam_step(*ptrs, self._steps, stream))
         # the library wrote the parameters behind torch's back: their version counters did not move, and the owner's
         # packed-image cache (IntrinsicModel.packed) is keyed on them -- drop it explicitly
         if hasattr(self.owner, "_packed"):

@@ -329,6 +329,15 @@ int grlhip_cep_loss_fwd_bwd(const grlhip_plan* plan, const void* packed, int dty
 int grlhip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                      float beta1, float beta2, float eps, float weight_decay, int64_t step, void* stream);
 
+/* grlhip_adam_step with the step count on the device, for training steps replayed from a captured HIP graph (a by-value
+ * `step` would be frozen into the graph): `step_record` points to 16 device bytes {int64 step; float; float}, zeroed by
+ * the caller before the first step.  advance != 0: a one-thread kernel first does ++step and derives the two bias
+ * corrections from it (in double, as grlhip_adam_step does on the host); advance == 0 reuses them (further parameter
+ * ranges of the same optimizer step).  Same update rule; the reference's counterpart is torch.optim.Adam(capturable=True). */
+int grlhip_adam_step_counted(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, void* step_record, int advance,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

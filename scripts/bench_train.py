@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="rows per GPU")
     ap.add_argument("--backward-split", type=int, default=3, choices=(2, 3),
                     help="bf16 pieces per fp32 value in the backward GEMMs (3 = fp32 rounding level, the default)")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the whole step once with torch.cuda.graph and time its replays (one GPU only)")
     args = ap.parse_args()
     from generativerl_preview_amd import launch
     if launch.needs_self_launch(args.gpus):   # nothing has touched the GPU yet
@@ -47,7 +49,8 @@ def main():
     m.model.backward_split = args.backward_split
     fg = attach_flat_grads(m.model)   # .grad of every parameter is a view of ONE flat buffer
     from generativerl_preview_amd.optim import FlatAdam
-    opt = FlatAdam(m.model, lr=1e-4)   # ONE launch over the flat parameter buffer (grlhip_adam_step)
+    use_graph = args.graph and world == 1
+    opt = FlatAdam(m.model, lr=1e-4, capturable=use_graph)   # ONE launch over the flat parameter buffer (grlhip_adam_step)
     B = args.batch
     gen = torch.Generator(device=device).manual_seed(1 + rank)
     x1 = torch.rand(B, 6, device=device, generator=gen) * 2 - 1
@@ -55,14 +58,30 @@ def main():
 
     def step():
         fg.zero()
-        x0 = torch.randn(B, 6, device=device, generator=gen)
+        x0 = torch.randn(B, 6, device=device) if use_graph else torch.randn(B, 6, device=device, generator=gen)
         loss = m.flow_matching_loss(x0, x1, cond)
         loss.backward()                      # one fused pass into the flat buffer
         gl_loss = fg.allreduce(B, loss)      # ONE in-place all-reduce (no-op at world 1)
         opt.step()
         return loss if gl_loss is None else gl_loss
 
-    elapsed, loss = ranks.timed(step, args.warmup, args.steps)
+    if use_graph:   # every launch of the step goes to the capture stream; the optimizer's step count lives on the device
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream(device).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_loss = step()
+
+        def replay():
+            graph.replay()
+            return static_loss
+        elapsed, loss = ranks.timed(replay, args.warmup, args.steps)
+    else:
+        elapsed, loss = ranks.timed(step, args.warmup, args.steps)
     import ctypes
     from generativerl_preview_amd import _lib as L
     launches = 0
@@ -78,7 +97,7 @@ def main():
             "metric": "training rows/sec (ICFM flow_matching_loss fwd+bwd+all-reduce+Adam)",
             "value": B * world * args.steps / elapsed, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic", "backward_split": args.backward_split,
+            "dtype": "f32", "data": "synthetic", "backward_split": args.backward_split, "hip_graph_replay": bool(use_graph),
             "config": {"workload": "C3 GMPO ICFM training step, batch %d per GPU, net [512,256,128], obs 17 / act 6, sigma 0.1" % B,
                        "parallelism": "data parallel x%d, one flat fp32 all-reduce per step" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
