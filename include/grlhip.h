@@ -195,9 +195,9 @@ int grlhip_sample_fixed(const grlhip_plan* plan, const void* packed, int dtype,
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* No counterpart in the reference.  For callers that cannot allocate device memory or hand over a workspace --
- * tight serving loops, harnesses that forbid hipMalloc, code that will later run under HIP graph capture (make the
- * first call on each device OUTSIDE a capture: it looks up the array's device address with hipGetSymbolAddress, which
- * may load the code object; capture itself is not covered by a test): grlhip_sample_ode on the fused
+ * tight serving loops, harnesses that forbid hipMalloc, code that runs under HIP graph capture (make the first call on
+ * each device OUTSIDE a capture: it looks up the array's device address with hipGetSymbolAddress, which may load the
+ * code object; after that the call captures and replays, guided or not: tests/test_zz_no_alloc.py): grlhip_sample_ode on the fused
  * bf16 integrator (GRLHIP_BF16 images of networks that have one; anything else: GRLHIP_ERR_UNSUPPORTED) with the
  * workspace (per-step Fourier tables, spliced guided weight stream) in a device array of GRLHIP_STATIC_SCRATCH_BYTES
  * that is part of the library's code object.  Each GPU the library runs on holds its own copy until the process ends.

@@ -87,3 +87,50 @@ def test_static_scratch_rejects_what_it_cannot_hold():
     rc = lib.grlhip_sample_ode_static(plan.handle, _ptr(m.model.packed(L.F32)), None, None, _ptr(x0), None, _ptr(coef),
                                       1, 4, _ptr(out), None, _stream(DEV))
     assert rc == -2, (rc, lib.grlhip_last_error())
+
+
+@pytest.mark.parametrize("guided", [False, True])
+def test_static_scratch_entry_point_under_hip_graph_capture(guided):
+    """The caller the entry point exists for: grlhip_sample_ode_static captured into a HIP graph (after one call outside
+    the capture, which resolves the scratch symbol) and replayed on new inputs written into the same buffers; every
+    replay equals grlhip_sample_ode on those inputs bit for bit."""
+    lib = L.lib()
+    kind, cfg, m = um.build("qgpo_noise", DEV)
+    g = m.energy_guidance.model if guided else None
+    rows, n_steps = 515, 9
+    coef = _table(m, n_steps, guided)
+    plan, packed = m.model.plan, m.model.packed(L.BF16)
+    g_h = g.plan.handle if guided else None
+    g_packed = g.packed(L.BF16) if guided else None
+    x0 = torch.zeros(rows, 6, device=DEV)
+    cond = torch.zeros(rows, 17, device=DEV)
+    got = torch.zeros(rows, 6, device=DEV)
+    want = torch.zeros(rows, 6, device=DEV)
+    need = lib.grlhip_workspace_bytes(plan.handle, g_h, rows, L.BF16)
+    ws = torch.empty(need, dtype=torch.uint8, device=DEV)
+
+    def static_call():
+        L.check(lib.grlhip_sample_ode_static(plan.handle, _ptr(packed), g_h, _ptr(g_packed), _ptr(x0), _ptr(cond),
+                                             _ptr(coef), n_steps, rows, _ptr(got), None, _stream(DEV)))
+    with torch.cuda.device(DEV):
+        static_call()                     # outside any capture: resolves the scratch symbol on this device
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream(device=DEV)
+        side.wait_stream(torch.cuda.current_stream(DEV))
+        with torch.cuda.stream(side):
+            static_call()
+        torch.cuda.current_stream(DEV).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_call()
+        gen = torch.Generator().manual_seed(21)
+        for _ in range(3):
+            x0.copy_(torch.randn(rows, 6, generator=gen))
+            cond.copy_(torch.randn(rows, 17, generator=gen))
+            got.fill_(float("nan"))
+            graph.replay()
+            L.check(lib.grlhip_sample_ode(plan.handle, _ptr(packed), L.BF16, g_h, _ptr(g_packed), _ptr(x0), _ptr(cond),
+                                          _ptr(coef), n_steps, rows, _ptr(want), None, _ptr(ws), ws.numel(), _stream(DEV)))
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(want).all())
+            assert torch.equal(got, want), float((got - want).abs().max())
