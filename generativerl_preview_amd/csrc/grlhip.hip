@@ -173,12 +173,10 @@ int grlhip_plan_program_info(const grlhip_plan* plan, int program, int32_t* n_op
   if (!plan || !plan->p || program < 0 || program > 3) return fail(GRLHIP_ERR_INVALID, "program must be 0..3");
   const Plan* p = plan->p;
   const std::vector<Op>& prog = program == 0 ? p->fwd : program == 1 ? p->grad : program == 2 ? p->train_fwd : p->train_bwd;
-  int launches = 0, reduces = 0;
-  for (size_t i = 0; i < prog.size(); ++i, ++launches) {
-    if (batch_fusable(p, prog, i)) ++i;
-    else if (prog[i].type == OP_DW || prog[i].type == OP_HEAD_BWD) ++reduces;   // partials now, ordered reduce at the end
-  }
-  launches += (reduces + bt::REDUCE_BATCH - 1) / bt::REDUCE_BATCH;                // one batched reduce per 24 gradients
+  // the engine's own schedule in count-only mode (nothing is dereferenced or launched)
+  static float dummy[4];
+  int launches = 0;
+  if (!prog.empty()) batch_run_program(p, prog, dummy, dummy, 128, dummy, nullptr, false, 0, 3, &launches);
   if (n_ops) *n_ops = (int32_t)prog.size();
   if (n_launches) *n_launches = launches;
   return 0;

@@ -173,7 +173,12 @@ Plan* build_plan(const grlhip_net_desc& d, std::string& err) {
       p->tr_gtc = t.alloc(d.t_dim + ch);
       const int g_zc = cond ? t.alloc(ch) : -1;
       const int hmax_t = *std::max_element(h, h + L_);
-      const int g_h1 = t.alloc(hmax_t), g_z = t.alloc(hmax_t), g_z1 = t.alloc(hmax_t), sM = t.alloc(hmax_t);
+      const int g_h1 = t.alloc(hmax_t), g_z1 = t.alloc(hmax_t), sM = t.alloc(hmax_t);
+      // dz2 of consecutive blocks alternates between two buffers: a block's last GEMM writes the NEXT block's dz2 while this
+      // block's weight gradients (queued by the engine until an operand is about to be overwritten, then ONE launch) still
+      // read its own
+      const int g_zs[2] = {t.alloc(hmax_t), t.alloc(hmax_t)};
+      int zsel = 0;
 
       struct Blk { int lt, l1, ld, lm, in, K, out, N, T, z1, h1, z2; };
       std::vector<Blk> blks;
@@ -210,6 +215,8 @@ Plan* build_plan(const grlhip_net_desc& d, std::string& err) {
       // out of the epilogue of this block's last GEMM (F_DSILU over the leading next->N features), so it starts with
       // dz2 already in g_z (dz2_ready) instead of an elementwise pass over dout
       auto bblock = [&](const Blk& k, int gout, int gin, int gin_mode, const Blk* next, bool dz2_ready) {
+        const int g_z = g_zs[zsel], g_z_next = g_zs[zsel ^ 1];
+        zsel ^= 1;
         if (k.lm >= 0) {
           dw(k.lm, gout, k.in);
           if (gin_mode) lin_t(k.lm, gout, gin, gin_mode == 2);
@@ -226,14 +233,14 @@ Plan* build_plan(const grlhip_net_desc& d, std::string& err) {
         if (gin_mode) {
           // gin (+)= W1^T dz1 (+ dout for an identity residual); g_z (this block's dz2) is dead by now
           const int flags = ((k.lm >= 0 || gin_mode == 2) ? F_ACCUM : 0) | (next ? F_DSILU : 0);
-          t.linear(TB, T_of(k.l1), g_z1, gin, k.lm >= 0 ? -1 : gout, flags, next ? g_z : -1, next ? next->z2 : -1, next ? next->N : 0);
+          t.linear(TB, T_of(k.l1), g_z1, gin, k.lm >= 0 ? -1 : gout, flags, next ? g_z_next : -1, next ? next->z2 : -1, next ? next->N : 0);
         }
       };
       const int llast = b.by_name["backbone.last_block"];
       dw(llast, p->tr_gout, catf[0]);
       // d cat[0] = W_last^T dout; the leading h[0] features are the output gradient of the block processed first, whose
       // dz2 = dout SiLU'(z2) comes out of the same epilogue (as between blocks, see bblock)
-      t.linear(TB, T_of(llast), p->tr_gout, gcat[0], -1, F_DSILU, g_z, blks.back().z2, blks.back().N);
+      t.linear(TB, T_of(llast), p->tr_gout, gcat[0], -1, F_DSILU, g_zs[0], blks.back().z2, blks.back().N);
       int bi = (int)blks.size() - 1;                              // blocks were pushed in forward order
       bool ready = true;
       for (int j = L_ - 2; j >= 0; --j, --bi) {                    // up blocks, reversed

@@ -41,8 +41,9 @@ def test_state_dict_matches_reference_keys(name):
     assert sorted(names) == sorted(k for k, _ in m.model.model.named_parameters())
 
 
-@pytest.mark.parametrize("name,blocks_with_modify,blocks", [("qgpo_noise", 3, 6), ("gvp_wide", 1, 2), ("swiss_noise", 3, 6)])
-def test_batch_engine_fuses_time_mlp_and_modify_x(name, blocks_with_modify, blocks):
+@pytest.mark.parametrize("name,blocks_with_modify,blocks,bwd_launches", [("qgpo_noise", 3, 6, 35), ("gvp_wide", 1, 2, 15),
+                                                                          ("swiss_noise", 3, 6, 33)])
+def test_batch_engine_fuses_time_mlp_and_modify_x(name, blocks_with_modify, blocks, bwd_launches):
     """The peephole of the batch engine: every residual block's time-MLP, and modify_x where the block changes
     width, become the second accumulator of the consuming GEMM; nothing in the backward program may fuse."""
     kind, cfg, m = um.build(name)
@@ -55,10 +56,14 @@ def test_batch_engine_fuses_time_mlp_and_modify_x(name, blocks_with_modify, bloc
     fused = blocks + blocks_with_modify
     assert info[0][0] - info[0][1] == fused, info
     assert info[2][0] - info[2][1] == fused, info
-    # backward: nothing fuses; every weight gradient writes per-slice partials, and ONE launch per 24 of them adds the
-    # slices in order at the end of the program
+    # backward: no dual GEMMs; the weight gradients wait until one of their operands is about to be overwritten and then
+    # go as ONE launch (a residual block's three or four together: 8 launches instead of 25 for the [512,256,128] net),
+    # every one writes per-slice partials, and ONE launch per 24 of them adds the slices in order at the end
     n_dw = sum(1 for n, _ in m.model.plan.params if n.endswith(".weight"))
-    assert info[3][0] > 0 and info[3][1] == info[3][0] + (n_dw + 23) // 24, (info, n_dw)
+    reduces = (n_dw + 23) // 24
+    assert info[3][0] > 0 and info[3][1] == bwd_launches, (info, n_dw)
+    dw_launches = info[3][1] - reduces - (info[3][0] - n_dw)
+    assert 1 <= dw_launches <= (n_dw + 2) // 3, (info, n_dw, dw_launches)
     assert info[1] == (0, 0)
 
 
@@ -74,7 +79,7 @@ def test_energy_net_plan_has_training_programs():
         n_ops, n_launch = ctypes.c_int32(), ctypes.c_int32()
         L.check(L.lib().grlhip_plan_program_info(plan.handle, prog, ctypes.byref(n_ops), ctypes.byref(n_launch)))
         info[prog] = (n_ops.value, n_launch.value)
-    assert info[2] == (3, 3) and info[3] == (6, 7), info   # 6 ops + the one batched ordered reduce of the 3 weight gradients
+    assert info[2] == (3, 3) and info[3] == (6, 6), info   # 4 ops + ONE launch for the 2 queued weight gradients + the one batched ordered reduce of the 3 gradients
     assert len(plan.params) == 7
     assert L.lib().grlhip_grad_numel(plan.handle) == 16 + 55 * 256 + 256 + 256 * 256 + 256 + 256 + 1
     assert L.lib().grlhip_loss_workspace_bytes(plan.handle, 4096, L.F32) > 0
