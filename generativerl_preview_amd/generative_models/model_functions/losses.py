@@ -35,6 +35,21 @@ def _draw_t(fn_owner, process, batch_size, device, weighting_scheme):
     raise NotImplementedError("Unknown weighting scheme {}".format(weighting_scheme))
 
 
+_CONST = {}
+
+
+def _const(value, n, dev):
+    """A constant fp32 vector of n elements (a unit alpha, a zero beta, the 1 / B row weights): read-only operands of
+    the library calls, built once per (value, n, device) instead of one fill launch per training step."""
+    key = (float(value), int(n), str(dev))
+    v = _CONST.get(key)
+    if v is None:
+        if len(_CONST) >= 64:
+            _CONST.clear()
+        v = _CONST[key] = torch.full((int(n),), float(value), dtype=torch.float32, device=dev)
+    return v
+
+
 def prepare_score_matching(owner, model_type, process, x, gaussian_generator, weighting_scheme, t=None, noise=None):
     B, dev = x.shape[0], x.device
     if t is None:
@@ -44,7 +59,7 @@ def prepare_score_matching(owner, model_type, process, x, gaussian_generator, we
     p = process.path
     std, scale = p.std(t), p.scale(t)
     x_t = _bc(scale, x) * x + _bc(std, x) * noise
-    one, zero = torch.ones_like(t), torch.zeros_like(t)
+    one, zero = _const(1.0, B, dev), _const(0.0, B, dev)
     if model_type == "noise_function":
         alpha, beta = one, zero
     elif model_type == "score_function":
@@ -70,7 +85,7 @@ def prepare_flow_matching(model_type, process, x, gaussian_generator, t=None, no
     std, scale = p.std(t), p.scale(t)
     x_t = _bc(scale, x) * x + _bc(std, x) * noise
     f, g2 = p.drift_coefficient(t), p.diffusion_squared(t)
-    one, zero = torch.ones_like(t), torch.zeros_like(t)
+    one, zero = _const(1.0, B, dev), _const(0.0, B, dev)
     if model_type == "noise_function":
         alpha, beta = 0.5 * g2 / std, f
     elif model_type == "score_function":
@@ -95,7 +110,7 @@ def prepare_icfm(process, x0, x1, t=None, noise=None):
     if noise is None:
         noise = torch.randn_like(x0)
     x_t = process.mean(t, x0, x1) + process.std(t, x0, x1) * noise
-    return t, x_t, torch.ones_like(t), torch.zeros_like(t), process.velocity(t, x0, x1)
+    return t, x_t, _const(1.0, B, dev), _const(0.0, B, dev), process.velocity(t, x0, x1)
 
 
 def _param_grads(model, flat, n_params):
@@ -172,7 +187,7 @@ class _FusedLoss(torch.autograd.Function):
         n_grad = lib.grlhip_grad_numel(plan.handle)
         need_grad = grad_mode and any(p.requires_grad for p in params)
         flat, ctx.token = _stage(model, n_grad, dev) if (need_grad and average) else (None, None)
-        roww = torch.full((B,), 1.0 / B, dtype=torch.float32, device=dev) if flat is not None else None
+        roww = _const(1.0 / B, B, dev) if flat is not None else None
         _launch(model, t, x_t, cond, alpha, beta, target, roww, loss_rows, flat)
         ctx.model, ctx.average, ctx.flat = model, average, flat
         ctx.n_params = len(params)
@@ -244,7 +259,7 @@ class _FusedCepLoss(torch.autograd.Function):
         loss_groups = torch.empty(G, dtype=torch.float32, device=dev)
         need_grad = grad_mode and any(p.requires_grad for p in params)
         flat, ctx.token = _stage(model, lib.grlhip_grad_numel(plan.handle), dev) if need_grad else (None, None)
-        gw = torch.full((G,), 1.0 / G, dtype=torch.float32, device=dev) if need_grad else None
+        gw = _const(1.0 / G, G, dev) if need_grad else None
         t, x_t, cond = _f32c(t, "t", (R,)), _f32c(x_t, "x_t", (R, plan.x_dim)), _f32c(cond, "condition")
         logits0 = _f32c(logits0, "logits0", (R,))
         ws = plan.train_workspace(R, dev)
