@@ -66,6 +66,16 @@ class FlatGrads:
     def zero(self):
         self.flat.zero_()
 
+    def clip_grad_norm_(self, max_norm: float, norm_type: float = 2.0):
+        """``torch.nn.utils.clip_grad_norm_`` over the owner's parameters (the swiss-roll training loop of the reference,
+        grl_pipelines/tutorials: ``clip_grad_norm_(model.parameters(), 1.0)``) on the ONE flat buffer their ``.grad``
+        alias: a norm, a clamp and a multiply instead of one norm per tensor -- same formula (``max_norm / (total +
+        1e-6)``, clamped to 1), no host synchronisation.  Returns the total norm (0-dim tensor)."""
+        g = self.grads
+        total = torch.linalg.vector_norm(g, float(norm_type))
+        g.mul_(torch.clamp(float(max_norm) / (total + 1e-6), max=1.0))
+        return total
+
     def allreduce(self, local_rows: int, local_loss=None, group=None):
         """Turn per-rank gradients of a mean over the LOCAL rows into the gradient of the mean over the GLOBAL batch
         (the reference's ``mean`` over all rows): weight by the local row count, ONE all-reduce(SUM) of the flat buffer

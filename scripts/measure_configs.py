@@ -40,6 +40,15 @@ def c1_train():
     torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0); opt.step()
 t = timed(c1_train, 5)
 report("C1 training step (score_matching_loss default weighting + clip + Adam), batch 4096", engine="f32", seconds=t, rows_per_s=4096 / t)
+# the same loop on flat buffers: FlatAdam (one launch) and the clip as one norm over the flat gradient buffer
+from generativerl_preview_amd.optim import FlatAdam
+m1 = G.DiffusionModel(dict(gl.diffusion_cfg(2, gl.VP, "noise_function", [512, 256, 128]), device=DEV)).to(DEV)
+fopt = FlatAdam(m1.model, lr=5e-3)
+def c1_train_flat():
+    fopt.zero_grad(); loss = m1.score_matching_loss(x); loss.backward()
+    fopt.fg.clip_grad_norm_(1.0); fopt.step()
+t = timed(c1_train_flat, 5)
+report("C1 training step, the same with FlatAdam + FlatGrads.clip_grad_norm_, batch 4096", engine="f32", seconds=t, rows_per_s=4096 / t)
 
 # C3: ICFM training step, batch 65536
 icfm = G.IndependentConditionalFlowModel(dict(gl.icfm_cfg(6, [512, 256, 128], 17), device=DEV)).to(DEV)

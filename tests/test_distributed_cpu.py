@@ -170,3 +170,30 @@ def test_bench_launches_its_own_ranks():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry", "--states", "16"],
                          env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0
+
+
+def test_flat_gradient_buffer_clip_equals_torch_clip_grad_norm():
+    """FlatGrads.clip_grad_norm_ (one norm over the flat buffer every .grad aliases) against
+    torch.nn.utils.clip_grad_norm_ over the same parameters: same total norm, same clipped gradients, with a norm above
+    and below the threshold."""
+    import copy
+    import util_models as um
+    from generativerl_preview_amd.distributed import attach_flat_grads
+    kind, cfg, m = um.build("small_icfm")
+    fg = attach_flat_grads(m.model, "cpu")
+    gen = torch.Generator().manual_seed(2)
+    for scale, max_norm in ((1.0, 1.0), (1e-4, 1.0), (3.0, 0.25)):
+        fg.zero()
+        fg.ensure()
+        for p in m.model.parameters():
+            if p.requires_grad:
+                p.grad.copy_(torch.randn(p.shape, generator=gen) * scale)
+        twin = [p.grad.detach().clone().requires_grad_(False) for p in m.model.parameters() if p.requires_grad]
+        params = [torch.nn.Parameter(torch.zeros_like(g)) for g in twin]
+        for q, g in zip(params, twin):
+            q.grad = g.clone()
+        want = torch.nn.utils.clip_grad_norm_(params, max_norm)
+        got = fg.clip_grad_norm_(max_norm)
+        assert abs(float(got) - float(want)) <= 1e-6 * float(want)
+        for q, p in zip(params, [p for p in m.model.parameters() if p.requires_grad]):
+            assert torch.allclose(p.grad, q.grad, rtol=1e-6, atol=1e-12)
