@@ -155,7 +155,7 @@ Plan* build_plan(const grlhip_net_desc& d, std::string& err) {
         o.in = in; o.add = dz; o.out = -1; o.pre = l.K; o.lin = lin;
         TB.push_back(o);
       };
-      auto lin_t = [&](int lin, int in, int out, bool accum) { t.linear(TB, T_of(lin), in, out, -1, accum ? F_ACCUM : 0); };
+      auto lin_t = [&](int lin, int in, int out, bool accum, int more = 0) { t.linear(TB, T_of(lin), in, out, -1, (accum ? F_ACCUM : 0) | more); };
       const int L_ = L;
       p->tr_temb = t.alloc(d.t_dim + ch);
       const int tc = p->tr_temb, cemb_t = tc + d.t_dim;
@@ -219,7 +219,8 @@ Plan* build_plan(const grlhip_net_desc& d, std::string& err) {
         zsel ^= 1;
         if (k.lm >= 0) {
           dw(k.lm, gout, k.in);
-          if (gin_mode) lin_t(k.lm, gout, gin, gin_mode == 2);
+          // (reads dout, writes d in: independent of the dense2 input gradient that follows)
+          if (gin_mode) lin_t(k.lm, gout, gin, gin_mode == 2, F_PAIR_NEXT);
         }
         // (identity residual, k.lm < 0: d in += d out rides as the residual operand of the dense1 GEMM below)
         if (!dz2_ready) t.eltwise(TB, OP_SILU_BWD, k.N, k.z2, g_z, gout);       // dz2 = dout * silu'(z2)
@@ -227,7 +228,8 @@ Plan* build_plan(const grlhip_net_desc& d, std::string& err) {
         // dh1 (= dT) and, from the same epilogue, dz1 = dh1 * silu'(z1) (g_z is this GEMM's input: dz1 -> g_z1)
         t.linear(TB, T_of(k.ld), g_z, g_h1, -1, F_DSILU, g_z1, k.z1);
         dw(k.lt, g_h1, ste_t);
-        lin_t(k.lt, g_h1, g_ste, ste_written);
+        // (reads dh1, adds into d ste: independent of the dense1 input gradient that follows)
+        lin_t(k.lt, g_h1, g_ste, ste_written, gin_mode ? F_PAIR_NEXT : 0);
         ste_written = true;
         dw(k.l1, g_z1, k.in);
         if (gin_mode) {

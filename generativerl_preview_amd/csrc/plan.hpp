@@ -39,7 +39,8 @@ enum OpFlags : int32_t { F_SILU_OUT = 1, F_SAVE_PRE = 2, F_ACCUM = 4, F_RELU_OUT
                          // (with F_RELU_OUT: ReLU' instead of SiLU'; with F_NO_OUT: out itself is not stored)
                          F_DSILU = 16, F_NO_OUT = 32,
                          // the op only feeds the gradient of the Fourier frequencies: skipped unless Plan::fourier_grad
-                         F_FOURIER_ONLY = 64 };
+                         F_FOURIER_ONLY = 64,
+                         F_PAIR_NEXT = 128 };   // independent of the next OP_LINEAR of the program: the engine may launch the two together
 
 struct Op {
   int32_t type, K, N, w, b, in, out, add, flags, pre;  // pre: where z (pre-activation) is kept (F_SAVE_PRE)

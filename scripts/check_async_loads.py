@@ -109,7 +109,7 @@ def main():
             text = open(out).read()
     failed = False
     seen = 0
-    for m in re.finditer(r"^(_ZN6grlhip2bt(?:12k_bt_gemm_x6|10k_bt_dw_x6|12k_bt_dw_many|18k_bt_gemm_bf16_big)\w+):[^\n]*\n", text, re.M):
+    for m in re.finditer(r"^(_ZN6grlhip2bt(?:12k_bt_gemm_x6|17k_bt_gemm_x6_pair|10k_bt_dw_x6|12k_bt_dw_many|18k_bt_gemm_bf16_big)\w+):[^\n]*\n", text, re.M):
         name = m.group(1)
         end = text.index(".end_amdhsa_kernel", m.end())
         body = text[m.end():end]

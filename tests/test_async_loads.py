@@ -20,4 +20,4 @@ def test_no_use_of_a_tile_register_before_its_wait():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_async_loads.py")],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("0 early uses") == 10, r.stdout   # six k_bt_gemm_x6 variants, two k_bt_dw_many, two k_bt_gemm_bf16_big
+    assert r.stdout.count("0 early uses") == 14, r.stdout   # six k_bt_gemm_x6 variants, four k_bt_gemm_x6_pair, two k_bt_dw_many, two k_bt_gemm_bf16_big

@@ -41,8 +41,8 @@ def test_state_dict_matches_reference_keys(name):
     assert sorted(names) == sorted(k for k, _ in m.model.model.named_parameters())
 
 
-@pytest.mark.parametrize("name,blocks_with_modify,blocks,bwd_launches", [("qgpo_noise", 3, 6, 35), ("gvp_wide", 1, 2, 15),
-                                                                          ("swiss_noise", 3, 6, 33)])
+@pytest.mark.parametrize("name,blocks_with_modify,blocks,bwd_launches", [("qgpo_noise", 3, 6, 28), ("gvp_wide", 1, 2, 14),
+                                                                          ("swiss_noise", 3, 6, 26)])
 def test_batch_engine_fuses_time_mlp_and_modify_x(name, blocks_with_modify, blocks, bwd_launches):
     """The peephole of the batch engine: every residual block's time-MLP, and modify_x where the block changes
     width, become the second accumulator of the consuming GEMM; nothing in the backward program may fuse."""
@@ -61,9 +61,10 @@ def test_batch_engine_fuses_time_mlp_and_modify_x(name, blocks_with_modify, bloc
     # every one writes per-slice partials, and ONE launch per 24 of them adds the slices in order at the end
     n_dw = sum(1 for n, _ in m.model.plan.params if n.endswith(".weight"))
     reduces = (n_dw + 23) // 24
+    # ... and two input-gradient GEMMs of a block that do not depend on each other (time-MLP beside dense1, modify_x
+    # beside dense2) go as one launch (k_bt_gemm_x6_pair)
     assert info[3][0] > 0 and info[3][1] == bwd_launches, (info, n_dw)
-    dw_launches = info[3][1] - reduces - (info[3][0] - n_dw)
-    assert 1 <= dw_launches <= (n_dw + 2) // 3, (info, n_dw, dw_launches)
+    assert info[3][1] < info[3][0] - n_dw + (n_dw + 2) // 3 + reduces, (info, n_dw)
     assert info[1] == (0, 0)
 
 
