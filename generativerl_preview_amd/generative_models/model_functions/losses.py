@@ -106,10 +106,17 @@ def prepare_icfm(process, x0, x1, t=None, noise=None):
     (stochastic_process.py:108-129): t = rand(B) * t_max, x_t = x0 (1-t) + x1 t + sigma * randn."""
     B, dev = x0.shape[0], x0.device
     if t is None:
-        t = torch.rand(B, device=dev) * process.t_max
+        t = torch.rand(B, device=dev)
+        if float(process.t_max) != 1.0:
+            t = t * process.t_max
     if noise is None:
         noise = torch.randn_like(x0)
-    x_t = process.mean(t, x0, x1) + process.std(t, x0, x1) * noise
+    sigma = getattr(getattr(process.path, "config", None), "sigma", None)
+    if sigma is not None and x0.dim() == 2 and t.dim() == 1:
+        # the same x_t in two launches instead of eight (interpolation, then + sigma * noise); fp32 rounding level
+        x_t = torch.add(torch.lerp(x0, x1, t.unsqueeze(1)), noise, alpha=float(sigma))
+    else:
+        x_t = process.mean(t, x0, x1) + process.std(t, x0, x1) * noise
     return t, x_t, _const(1.0, B, dev), _const(0.0, B, dev), process.velocity(t, x0, x1)
 
 
