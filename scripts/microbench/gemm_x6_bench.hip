@@ -59,6 +59,18 @@ int main(int argc, char** argv) {
     printf("stages %d ld %lld mode %d (%s): %.1f us  %.1f TFLOP/s fp32-equivalent  %.2f TB/s min traffic\n", ns, (long long)ld, mode,
            mode == 0 ? "plain" : mode == 1 ? "silu+pre" : "silu+pre+add", us, 2.0 * M * K * ld / us * 1e-6,
            ((double)(K + M * (1 + (mode >= 1) + (mode >= 2))) * ld * 4) / us * 1e-6);
+#ifdef GEMM_STAMPS
+    if (ns == 4) {   // -DGEMM_STAMPS: where wave 0 of a workgroup spends its time (s_memtime ticks, mean over the workgroups)
+      unsigned long long z[8] = {0};
+      hipMemcpyToSymbol(HIP_SYMBOL(bt::gemm_dbg), z, sizeof z);
+      launch();
+      hipDeviceSynchronize();
+      hipMemcpyFromSymbol(z, HIP_SYMBOL(bt::gemm_dbg), sizeof z);
+      const double n = (double)z[6];
+      printf("  per workgroup: prologue %.0f, k-loop %.0f (barrier wait %.0f, load wait %.0f), epilogue %.0f, whole %.0f ticks; MFMA time of the k-loop at 32 cycles each: %d\n",
+             z[0] / n, z[1] / n, z[2] / n, z[3] / n, z[4] / n, z[5] / n, (K / 16) * 24 * 32);
+    }
+#endif
   }
   {  // the pipelined kernel accumulates the same products in the same order: bit-identical outputs expected
     bt::GemmArgs g{};
