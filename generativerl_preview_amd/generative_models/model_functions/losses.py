@@ -44,9 +44,12 @@ def _const(value, n, dev):
     key = (float(value), int(n), str(dev))
     v = _CONST.get(key)
     if v is None:
-        if len(_CONST) >= 64:
-            _CONST.clear()
-        v = _CONST[key] = torch.full((int(n),), float(value), dtype=torch.float32, device=dev)
+        v = torch.full((int(n),), float(value), dtype=torch.float32, device=dev)
+        # a fill recorded into a HIP graph under capture has not run yet: such a tensor is not kept for eager callers
+        if not (v.is_cuda and torch.cuda.is_current_stream_capturing()):
+            if len(_CONST) >= 64:
+                _CONST.clear()
+            _CONST[key] = v
     return v
 
 
