@@ -134,6 +134,18 @@ def test_adam_step_validates_its_arguments_without_a_gpu():
     plan.set_fourier_grad(False)
     assert plan.fourier_grad is False
     assert lib.grlhip_plan_set_fourier_grad(None, 1) != 0
+    # the device-counted variant: a null or misaligned step record is refused before anything is launched
+    assert lib.grlhip_adam_step_counted(ptr, ptr, ptr, ptr, 16, 1e-3, 0.9, 0.999, 1e-8, 0.0, None, 1, None) != 0
+    assert b"step_record" in lib.grlhip_last_error()
+    odd = ctypes.c_void_p(ctypes.addressof(buf) + 4)
+    assert lib.grlhip_adam_step_counted(ptr, ptr, ptr, ptr, 16, 1e-3, 0.9, 0.999, 1e-8, 0.0, odd, 0, None) != 0
+    # the backward split is 2 or 3
+    assert plan.backward_split == 3
+    plan.set_backward_split(2)
+    assert plan.backward_split == 2
+    with pytest.raises(L.GrlHipError):
+        plan.set_backward_split(1)
+    assert lib.grlhip_plan_set_backward_split(None, 2) != 0
 
 
 def test_stage_backward_rejects_bad_arguments_without_a_gpu():

@@ -127,3 +127,32 @@ def test_gpu_training_step_replays_from_a_captured_hip_graph():
     pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
     for k in pa:
         assert torch.equal(pa[k], pb[k]), k
+
+
+@pytest.mark.gpu
+def test_gpu_capturable_flat_adam_matches_the_host_counted_one_and_restores_its_state():
+    """FlatAdam(capturable=True) -- step count and bias corrections on the device -- takes the same steps as the
+    host-counted optimizer (both derive the corrections in double), and a state_dict round trip restores the count."""
+    from generativerl_preview_amd.optim import FlatAdam
+    name = "small_icfm"
+    kind, cfg, a = um.build(name, DEV)
+    kind, cfg, b = um.build(name, DEV)
+    b.load_state_dict(copy.deepcopy(a.state_dict()))
+    oa, ob = FlatAdam(a.model, lr=1e-3, weight_decay=0.01), FlatAdam(b.model, lr=1e-3, weight_decay=0.01, capturable=True)
+    gen = torch.Generator().manual_seed(1)
+    B = 257
+    for _ in range(5):
+        x0, x1 = torch.randn(B, 6, generator=gen).to(DEV), torch.rand(B, 6, generator=gen).to(DEV)
+        cond, t, eps = torch.randn(B, 17, generator=gen).to(DEV), torch.rand(B, generator=gen).to(DEV), torch.randn(B, 6, generator=gen).to(DEV)
+        for m, o in ((a, oa), (b, ob)):
+            o.zero_grad()
+            m.flow_matching_loss(x0, x1, cond, t=t, noise=eps).backward()
+            o.step()
+    assert oa.step_count == ob.step_count == 5
+    for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(p, q), k
+    sd = ob.state_dict()
+    ob.step_count = 0
+    assert ob.step_count == 0
+    ob.load_state_dict(sd)
+    assert ob.step_count == 5
