@@ -630,6 +630,12 @@ int grlhip_adam_step_counted(float* params, const float* grads, float* exp_avg, 
 
 }  // extern "C"
 
+#ifdef GEMM_STAMPS
+extern "C" int grlhip_dbg_gemm(unsigned long long* dst, int reset) {   // experiment builds only (scripts/gemm_clock.py)
+  if (reset) { unsigned long long z[8] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(grlhip::bt::gemm_dbg), z, sizeof z); }
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(grlhip::bt::gemm_dbg), sizeof(unsigned long long) * 8);
+}
+#endif
 #ifdef WIDE_STAMPS
 extern "C" int grlhip_dbg_wide(unsigned long long* dst) {   // experiment builds only
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(grlhip::wd::wide_dbg), sizeof(unsigned long long) * 1024 * 8);
