@@ -43,6 +43,7 @@ PROTOTYPES = {
                                               ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
     "grlhip_plan_set_fourier_grad": (ctypes.c_int, [_vp, ctypes.c_int]),
     "grlhip_plan_set_backward_split": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "grlhip_plan_schedule_check": (ctypes.c_int, [_vp, ctypes.c_int]),
     "grlhip_plan_program_info": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
     "grlhip_bf16_fused_kernel": (ctypes.c_int, [_vp, _vp, ctypes.c_char_p, ctypes.c_size_t]),
     "grlhip_packed_bytes": (_sz, [_vp, ctypes.c_int]),

@@ -182,6 +182,13 @@ int grlhip_plan_program_info(const grlhip_plan* plan, int program, int32_t* n_op
   return 0;
 }
 
+int grlhip_plan_schedule_check(const grlhip_plan* plan, int program) {
+  if (!plan || !plan->p || program < 0 || program > 3) return fail(GRLHIP_ERR_INVALID, "program must be 0..3");
+  const Plan* p = plan->p;
+  const std::vector<Op>& prog = program == 0 ? p->fwd : program == 1 ? p->grad : program == 2 ? p->train_fwd : p->train_bwd;
+  return program_schedule_violation(p, prog);
+}
+
 int grlhip_plan_set_fourier_grad(grlhip_plan* plan, int enable) {
   if (!plan || !plan->p) return fail(GRLHIP_ERR_INVALID, "null plan");
   plan->p->fourier_grad = enable != 0;

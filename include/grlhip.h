@@ -91,6 +91,13 @@ int grlhip_plan_param_info(const grlhip_plan* plan, int index, char* name_buf, s
  * plan: do not change it while a call on the same plan is in progress on another thread. */
 int grlhip_plan_set_fourier_grad(grlhip_plan* plan, int enable);
 
+/* Introspection for the tests (no counterpart in the reference): the engine launches some ops of a program out of program
+ * order -- weight gradients are held back and launched together, two independent GEMMs go as one launch.  This replays
+ * the launch schedule of a program (0..3 as in grlhip_plan_program_info) without launching anything and checks it against
+ * the program's sequential meaning (every read-after-write, write-after-write and write-after-read pair of ops keeps
+ * its order).  Returns 0, or 1 + the index of the first op that would run too early (negative: invalid arguments). */
+int grlhip_plan_schedule_check(const grlhip_plan* plan, int program);
+
 /* No counterpart in the reference (its GPU matmuls are whatever precision torch is configured for).  The fp32 engine
  * forms every fp32 product from bf16 pieces on the matrix cores: three pieces per value, six MFMAs per product = fp32
  * rounding level.  pieces == 2 (three MFMAs per product, |error| <= ~2^-16 of each product,
